@@ -1,0 +1,191 @@
+/*
+ * rt.h — C ABI of the MI355X-native render path (librt_amd.so).
+ *
+ * The reference (cwbriones/raytracer, Rust) has no FFI; its per-pixel render
+ * path sits behind three crate-internal calls made from src/main.rs:
+ *     scene::load_scene(path, aspect, use_bvh)      main.rs:100  load.rs:39
+ *     camera.get_ray(rng, u, v)                     main.rs:174  camera.rs:76
+ *     scene.ray_color(ray, rng, max_depth)          main.rs:175  scene/mod.rs:79
+ * wrapped by the rayon pixel loop main.rs:150-185 and the tonemap main.rs:178-180.
+ * The cut is below the loader and above the pixel loop: the host hands over a
+ * flat immutable scene, the backend returns an un-normalised f32 radiance-sum
+ * framebuffer.  Every entry point is extern "C", plain pointers and sizes.
+ *
+ * Conventions: every call returning int returns 0 on success, non-zero on
+ * error; rt_last_error() then returns a thread-local message.  The caller owns
+ * all host buffers; handles are opaque and released by the matching destroy.
+ * A handle is used from one host thread at a time.
+ */
+#ifndef RT_AMD_RT_H
+#define RT_AMD_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- flat scene description (host memory, f64 like the reference: geom.rs:19,114) ---- */
+
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3 };
+enum { RT_SURF_SPHERE = 0, RT_SURF_TRIANGLE = 1, RT_SURF_QUAD = 2 };
+
+/* material.rs:16-56 (kind + SolidColor albedo; param = fuzz | refractive index) */
+typedef struct rt_material {
+    int32_t kind;
+    int32_t _pad;
+    double albedo[3];
+    double param;
+} rt_material;
+
+/* surfaces.rs:26-41 (stationary sphere; radius may be negative, distant.yaml:31) */
+typedef struct rt_sphere {
+    double center[3];
+    double radius;
+    int32_t material;
+    int32_t _pad;
+} rt_sphere;
+
+/* surfaces.rs:195-243: the three vertices and vertex normals a Triangle resolves through its Mesh */
+typedef struct rt_triangle {
+    double v[3][3];
+    double n[3][3];
+    int32_t material;
+    int32_t _pad;
+} rt_triangle;
+
+/* surfaces.rs:296-327: q,u,v as given; normal,d,w are the caches Quad::new computes */
+typedef struct rt_quad {
+    double q[3], u[3], v[3];
+    double normal[3];
+    double d;
+    double w[3];
+    int32_t material;
+    int32_t _pad;
+} rt_quad;
+
+/* One entry per surface in the order the loader added it to the SceneBuilder
+ * (load.rs:57-158).  Order matters: the BVH build uses a stable sort (bvh.rs:218).
+ * A primitive id reported by this library is an index into this array. */
+typedef struct rt_surface_ref {
+    int32_t type;  /* RT_SURF_* */
+    int32_t index; /* into spheres / triangles / quads */
+} rt_surface_ref;
+
+/* camera.rs:11-18 after Camera::new (camera.rs:43-74) */
+typedef struct rt_camera {
+    double origin[3], lower_left[3], horizontal[3], vertical[3];
+    double u[3], v[3], w[3];
+    double lens_radius;
+} rt_camera;
+
+typedef struct rt_scene_desc {
+    const rt_material* materials;
+    size_t n_materials;
+    const rt_sphere* spheres;
+    size_t n_spheres;
+    const rt_triangle* triangles;
+    size_t n_triangles;
+    const rt_quad* quads;
+    size_t n_quads;
+    const rt_surface_ref* surfaces;
+    size_t n_surfaces;
+    double background[3];
+    rt_camera camera;
+    int32_t use_bvh; /* 0 = one leaf holding every surface (--no-bvh, main.rs:60-65, scene/mod.rs:61-65) */
+    int32_t _pad;
+} rt_scene_desc;
+
+/* ---- host-side loader: replaces scene::load_scene (load.rs:39-160) ---- */
+
+/* Parses the scene YAML, loads OBJ(.gz) meshes, bakes transforms, builds the camera for
+ * `aspect_ratio`.  *out is owned by the library; release with rt_scene_desc_free. */
+int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_scene_desc** out);
+void rt_scene_desc_free(rt_scene_desc* desc);
+
+/* ---- device scene: BVH build (bvh.rs:131-234) + SoA flattening + upload to HBM ---- */
+
+typedef struct rt_scene rt_scene;
+
+/* device >= 0: that HIP device; RT_DEVICE_CURRENT keeps the current one; RT_DEVICE_NONE builds and
+ * flattens on the host only (inspection and CPU tests) — every render call on such a scene fails. */
+enum { RT_DEVICE_CURRENT = -1, RT_DEVICE_NONE = -2 };
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+typedef struct rt_scene_info {
+    uint64_t n_surfaces, n_nodes, n_leaves;
+    uint32_t max_depth;     /* depth of the binary tree (root = 1) */
+    uint32_t max_leaf_size; /* largest leaf (can exceed 8: bvh.rs:219,233) */
+    uint64_t device_bytes;  /* bytes resident in HBM for this scene */
+    double build_ms;        /* host BVH build + flatten */
+} rt_scene_info;
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* info);
+
+/* In-order (left-to-right) leaf sequence of the reference-topology tree as surface ids
+ * (n_surfaces entries) — the sequence that decides equal-t ties (bvh.rs:272-273,308). */
+int rt_scene_leaf_order(const rt_scene* scene, int32_t* out_surface_ids);
+
+/* ---- the hot path: replaces the pixel loop main.rs:150-185 ---- */
+
+enum { RT_KERNEL_PERSISTENT = 0, RT_KERNEL_WAVEFRONT = 1 };
+
+typedef struct rt_render_params {
+    uint32_t width, height;
+    uint32_t sn;             /* strata per axis: floor(sqrt(spp)), main.rs:142 */
+    uint32_t max_depth;      /* 40 in the reference, main.rs:118 */
+    uint64_t seed;
+    uint32_t stratum_begin;  /* this call renders strata k = begin, begin+step, ... < sn*sn   */
+    uint32_t stratum_step;   /* (k = si*sn + sj, main.rs:165-166); 0 is treated as 1          */
+    int32_t kernel;          /* RT_KERNEL_* */
+    int32_t collect_stats;   /* non-zero: count node visits / primitive tests (slower build of the kernel) */
+} rt_render_params;
+
+typedef struct rt_stats {
+    uint64_t samples;        /* camera paths traced by this call */
+    uint64_t segments;       /* ray segments traced incl. bounces ("rays" in the bounce sense) */
+    uint64_t node_visits;    /* BVH nodes whose child boxes were tested   (collect_stats only) */
+    uint64_t tri_tests, sphere_tests, quad_tests; /* primitive tests      (collect_stats only) */
+    double kernel_ms;        /* device time of the render kernels, HIP events on the launch stream */
+    uint32_t n_launches;     /* kernels launched */
+    uint32_t _pad;
+} rt_stats;
+
+/* Renders into DEVICE memory: d_rgb_sum = 3*width*height floats, row 0 = top row of the image
+ * (pj = height - idx/width - 1, main.rs:158), un-normalised radiance SUM over the strata of this
+ * call (overwritten, not accumulated).  `stream` is a hipStream_t (NULL = default stream); the call
+ * returns after enqueueing unless stats != NULL, in which case it synchronises the stream. */
+int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream,
+                     rt_stats* stats);
+
+/* Same, into HOST memory (synchronous; allocates and frees a device framebuffer). */
+int rt_render(rt_scene* scene, const rt_render_params* params, float* rgb_sum, rt_stats* stats);
+
+/* Parity AOV: closest hit of the pixel-centre ray (u=(pi+1)/W, v=(pj+1)/H, main.rs:161-162; no jitter,
+ * no lens offset), interval (0.001, inf) (scene/mod.rs:104).  prim_id = surface id or -1.
+ * precision: 64 = f64 arithmetic, no contraction, reference visiting rule (exact vs the oracle);
+ *            32 = the f32 arithmetic and pruned traversal the render kernels use. */
+int rt_primary_hits(rt_scene* scene, uint32_t width, uint32_t height, int precision, int32_t* prim_id,
+                    double* t);
+
+/* average + gamma-2 + quantise, main.rs:177-180,209-221: u8 = (256*clamp(sqrt(sum/n),0,0.999)) as u8,
+ * NaN -> 0.  Host buffers; runs on the current device. */
+int rt_tonemap_rgb8(const float* rgb_sum, uint32_t width, uint32_t height, uint64_t n_samples, uint8_t* out);
+/* Device-buffer form on a stream. */
+int rt_tonemap_rgb8_device(const float* d_rgb_sum, uint32_t width, uint32_t height, uint64_t n_samples,
+                           uint8_t* d_out, void* stream);
+
+/* ---- image output: replaces the png crate use at main.rs:192-200 (RGB8, row 0 = top) ---- */
+int rt_write_png(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height);
+
+/* The reference's loader reports mesh statistics on stderr (load.rs:231-244); off by default here. */
+void rt_set_verbose(int verbose);
+
+const char* rt_last_error(void);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_RT_H */

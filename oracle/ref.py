@@ -1,0 +1,138 @@
+"""ctypes wrapper of oracle/librt_ref.so — TEST INFRASTRUCTURE (tests/, smoke(), bench.py's cpu_baseline
+leg only).  ``RefScene.from_yaml`` goes through oracle/loader_ref.py, i.e. nothing here touches product code."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import loader_ref
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_ref.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `make -C oracle`")
+        L = C.CDLL(LIB_PATH)
+        vp, dp = C.c_void_p, C.c_void_p
+        L.ref_scene_create.restype = vp
+        L.ref_scene_create.argtypes = [dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
+                                       C.c_size_t, dp, dp, C.c_int]
+        L.ref_scene_destroy.argtypes = [vp]
+        L.ref_leaf_order.argtypes = [vp, dp, dp]
+        L.ref_camera.argtypes = [vp, dp]
+        L.ref_primary_hits.argtypes = [vp, C.c_uint32, C.c_uint32, dp, dp, C.c_int]
+        L.ref_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
+                                 C.c_uint32, C.c_int, dp, dp]
+        L.ref_tonemap.argtypes = [dp, C.c_size_t, C.c_double, dp]
+        L.ref_aabb_surface_area.restype = C.c_double
+        L.ref_aabb_surface_area.argtypes = [dp, dp]
+        L.ref_aabb_centroid.argtypes = [dp, dp, dp]
+        L.ref_sphere_bbox.argtypes = [dp, C.c_double, dp]
+        L.ref_aabb_hit.restype = C.c_int
+        L.ref_aabb_hit.argtypes = [dp, dp, dp, dp, C.c_double, C.c_double]
+        L.ref_trace.restype = C.c_int
+        L.ref_trace.argtypes = [vp, dp, dp, C.c_double, C.c_double, dp]
+        L.ref_scatter.restype = C.c_int
+        L.ref_scatter.argtypes = [C.c_int, dp, C.c_double, dp, dp, C.c_int, C.c_uint64, dp]
+        L.ref_reflectance.restype = C.c_double
+        L.ref_reflectance.argtypes = [C.c_double, C.c_double]
+        L.ref_rng_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, dp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def _d(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+class RefScene:
+    def __init__(self, flat: "loader_ref.FlatScene", use_bvh=True):
+        self.flat = flat
+        m, s, t, q = _d(flat.materials), _d(flat.spheres), _d(flat.triangles), _d(flat.quads)
+        sf = np.ascontiguousarray(flat.surfaces, dtype=np.int32)
+        bg, cam = _d(flat.background), _d(flat.camera)
+        self.n_surfaces = len(sf)
+        self._h = lib().ref_scene_create(_p(m), len(m), _p(s), len(s), _p(t), len(t), _p(q), len(q), _p(sf), len(sf),
+                                         _p(bg), _p(cam), 1 if use_bvh else 0)
+        if not self._h:
+            raise RuntimeError("ref_scene_create failed (bad surface index)")
+
+    @classmethod
+    def from_yaml(cls, path, aspect_ratio, use_bvh=True):
+        return cls(loader_ref.load_scene(path, aspect_ratio), use_bvh)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ref_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def leaf_order(self):
+        out = np.empty(self.n_surfaces, dtype=np.int32)
+        st = np.zeros(4, dtype=np.uint32)
+        lib().ref_leaf_order(self._h, _p(out), _p(st))
+        return out, dict(nodes=int(st[0]), leaves=int(st[1]), depth=int(st[2]), max_leaf=int(st[3]))
+
+    def camera(self):
+        out = np.zeros(22)
+        lib().ref_camera(self._h, _p(out))
+        names = ["origin", "lower_left", "horizontal", "vertical", "u", "v", "w"]
+        d = {n: out[3 * i:3 * i + 3].copy() for i, n in enumerate(names)}
+        d["lens_radius"] = float(out[21])
+        return d
+
+    def primary_hits(self, width, height, threads=8):
+        ids = np.empty((height, width), dtype=np.int32)
+        t = np.empty((height, width), dtype=np.float64)
+        lib().ref_primary_hits(self._h, width, height, _p(ids), _p(t), threads)
+        return ids, t
+
+    def render(self, width, height, sn, max_depth=40, seed=1, stratum_begin=0, stratum_step=1, threads=8):
+        out = np.empty((height, width, 3), dtype=np.float64)
+        cnt = np.zeros(5, dtype=np.uint64)
+        lib().ref_render(self._h, width, height, sn, max_depth, seed, stratum_begin, stratum_step, threads, _p(out),
+                         _p(cnt))
+        names = ["box_tests", "tri_tests", "sphere_tests", "quad_tests", "segments"]
+        return out, {n: int(c) for n, c in zip(names, cnt)}
+
+    def trace(self, o, d, tmin=0.001, tmax=np.inf):
+        o, d, out = _d(o), _d(d), np.zeros(8)
+        sid = lib().ref_trace(self._h, _p(o), _p(d), tmin, tmax, _p(out))
+        if sid < 0:
+            return None
+        return dict(surface=sid, t=out[0], point=out[1:4].copy(), normal=out[4:7].copy(), front_face=bool(out[7]))
+
+
+def tonemap(rgb_sum, n_samples):
+    a = _d(rgb_sum)
+    out = np.empty(a.shape, dtype=np.uint8)
+    lib().ref_tonemap(_p(a), a.size, float(n_samples), _p(out))
+    return out
+
+
+def scatter(kind, albedo, param, direction, normal, front_face, rng_state):
+    a, d, n, out = _d(albedo), _d(direction), _d(normal), np.zeros(6)
+    ok = lib().ref_scatter(kind, _p(a), param, _p(d), _p(n), 1 if front_face else 0, rng_state, _p(out))
+    return (out[:3].copy(), out[3:].copy()) if ok else None
+
+
+def rng_stream(seed, pixel, stratum, n):
+    out = np.zeros(n)
+    lib().ref_rng_stream(seed, pixel, stratum, n, _p(out))
+    return out

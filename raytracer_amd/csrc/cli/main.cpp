@@ -1,0 +1,206 @@
+// `raytracer` — command line of the reference (clap derive, main.rs:23-66) over the C ABI in include/rt.h.
+// Same flag names, defaults and conflict rule; same stderr "Done in …" line (main.rs:190) and RGB8 PNG
+// (main.rs:192-200).  Extra flags: --gpus N, --kernel persistent|wavefront, --dump-primary FILE, --json.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/rt.h"
+
+namespace {
+
+struct Opt {
+    size_t num_samples = 4;
+    std::string output = "output.png";
+    size_t threads = 0;
+    size_t width = 400;
+    bool has_height = false, has_aspect = false, has_seed = false, has_scene = false, has_example = false;
+    size_t height = 0;
+    double aspect_ratio = 1.5;
+    uint64_t seed = 0;
+    std::string scene, example, dump_primary;
+    bool no_progress = false, no_bvh = false, json = false;
+    int gpus = 1;
+    int kernel = RT_KERNEL_PERSISTENT;
+};
+
+[[noreturn]] void usage_error(const std::string& m) {
+    std::fprintf(stderr, "error: %s\n\nUsage: raytracer [OPTIONS]\n\nFor more information, try '--help'.\n", m.c_str());
+    std::exit(2);
+}
+
+void help() {
+    std::puts(
+        "A simple ray tracer implementation (MI355X-native render path).\n\n"
+        "Usage: raytracer [OPTIONS]\n\nOptions:\n"
+        "  -n, --num-samples <NUM_SAMPLES>    Number of samples to take per pixel [default: 4]\n"
+        "  -o, --output <OUTPUT>              Destination of the output image (png) [default: output.png]\n"
+        "  -t, --threads <THREADS>            Accepted for compatibility; the render runs on the GPU\n"
+        "      --width <WIDTH>                Output image width [default: 400]\n"
+        "      --height <HEIGHT>              Output image height\n"
+        "      --aspect-ratio <ASPECT_RATIO>  Output image aspect ratio [default: 1.5]\n"
+        "      --seed <SEED>                  Seed to use for RNG\n"
+        "      --scene <SCENE>                A scene file to load from configuration\n"
+        "      --example <EXAMPLE>            (not supported: procedural book scenes are outside this build)\n"
+        "      --no-progress                  Accepted for compatibility\n"
+        "      --no-bvh                       Disables the use of the bvh acceleration structure\n"
+        "      --gpus <N>                     Shard the strata over N GPUs [default: 1]\n"
+        "      --kernel <persistent|wavefront>\n"
+        "      --dump-primary <FILE>          Write the f64 primary-hit AOV (int32 ids, then f64 t) and exit\n"
+        "      --json                         Print a JSON metrics line on stdout\n"
+        "  -h, --help                         Print help");
+}
+
+Opt parse(int argc, char** argv) {
+    Opt o;
+    auto need = [&](int& i, const char* flag) -> std::string {
+        std::string a = argv[i];
+        size_t eq = a.find('=');
+        if (a.rfind("--", 0) == 0 && eq != std::string::npos) return a.substr(eq + 1);
+        if (i + 1 >= argc) usage_error(std::string("a value is required for '") + flag + "' but none was supplied");
+        return argv[++i];
+    };
+    auto to_size = [&](const std::string& s, const char* flag) -> size_t {
+        char* end = nullptr;
+        if (s.empty() || s[0] == '-') usage_error("invalid value '" + s + "' for '" + flag + "'");
+        unsigned long long v = std::strtoull(s.c_str(), &end, 10);
+        if (*end) usage_error("invalid value '" + s + "' for '" + flag + "'");
+        return (size_t)v;
+    };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        std::string key = a.substr(0, a.find('='));
+        if (key == "-h" || key == "--help") {
+            help();
+            std::exit(0);
+        } else if (key == "-n" || key == "--num-samples") o.num_samples = to_size(need(i, "--num-samples"), "--num-samples");
+        else if (key == "-o" || key == "--output") o.output = need(i, "--output");
+        else if (key == "-t" || key == "--threads") o.threads = to_size(need(i, "--threads"), "--threads");
+        else if (key == "--width") o.width = to_size(need(i, "--width"), "--width");
+        else if (key == "--height") o.height = to_size(need(i, "--height"), "--height"), o.has_height = true;
+        else if (key == "--aspect-ratio") {
+            std::string v = need(i, "--aspect-ratio");
+            char* end = nullptr;
+            o.aspect_ratio = std::strtod(v.c_str(), &end);
+            if (*end || v.empty()) usage_error("invalid value '" + v + "' for '--aspect-ratio'");
+            o.has_aspect = true;
+        } else if (key == "--seed") o.seed = to_size(need(i, "--seed"), "--seed"), o.has_seed = true;
+        else if (key == "--scene") o.scene = need(i, "--scene"), o.has_scene = true;
+        else if (key == "--example") o.example = need(i, "--example"), o.has_example = true;
+        else if (key == "--no-progress") o.no_progress = true;
+        else if (key == "--no-bvh") o.no_bvh = true;
+        else if (key == "--json") o.json = true;
+        else if (key == "--gpus") o.gpus = (int)to_size(need(i, "--gpus"), "--gpus");
+        else if (key == "--dump-primary") o.dump_primary = need(i, "--dump-primary");
+        else if (key == "--kernel") {
+            std::string v = need(i, "--kernel");
+            if (v == "persistent") o.kernel = RT_KERNEL_PERSISTENT;
+            else if (v == "wavefront") o.kernel = RT_KERNEL_WAVEFRONT;
+            else usage_error("invalid value '" + v + "' for '--kernel'");
+        } else usage_error("unexpected argument '" + a + "' found");
+    }
+    if (o.has_height && o.has_aspect)  // #[arg(long, conflicts_with = "height")], main.rs:44
+        usage_error("the argument '--aspect-ratio <ASPECT_RATIO>' cannot be used with '--height <HEIGHT>'");
+    return o;
+}
+
+int die(const char* ctx) {
+    std::fprintf(stderr, "Error: %s%s%s\n", ctx, *ctx ? ": " : "", rt_last_error());
+    return 1;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Opt o = parse(argc, argv);
+    // TracerOpt::height / aspect_ratio, main.rs:77-95
+    const size_t width = o.width;
+    const size_t height = o.has_height ? o.height : (size_t)((double)width / o.aspect_ratio);
+    const double aspect = o.has_height ? (double)width / (double)o.height : o.aspect_ratio;
+    const uint32_t max_depth = 40;  // main.rs:118
+    if (!o.has_scene) {
+        std::fprintf(stderr,
+                     "Error: --scene is required: the procedural --example scenes (default `one-weekend`) are outside "
+                     "this build's scope (SURVEY.md §8f)\n");
+        return 1;
+    }
+    if (o.gpus < 1) o.gpus = 1;
+    const auto start = std::chrono::steady_clock::now();
+    rt_set_verbose(1);
+
+    rt_scene_desc* desc = nullptr;
+    if (rt_load_scene(o.scene.c_str(), aspect, o.no_bvh ? 0 : 1, &desc)) return die("");
+    std::vector<rt_scene*> scenes((size_t)o.gpus, nullptr);
+    for (int g = 0; g < o.gpus; ++g)
+        if (rt_scene_create(desc, g, &scenes[(size_t)g])) return die("create device scene");
+
+    if (!o.dump_primary.empty()) {
+        std::vector<int32_t> ids(width * height);
+        std::vector<double> t(width * height);
+        if (rt_primary_hits(scenes[0], (uint32_t)width, (uint32_t)height, 64, ids.data(), t.data())) return die("primary hits");
+        FILE* f = std::fopen(o.dump_primary.c_str(), "wb");
+        if (!f) {
+            std::perror(o.dump_primary.c_str());
+            return 1;
+        }
+        std::fwrite(ids.data(), sizeof(int32_t), ids.size(), f);
+        std::fwrite(t.data(), sizeof(double), t.size(), f);
+        std::fclose(f);
+        return 0;
+    }
+
+    // main.rs:142: stratification needs a perfect square
+    const uint32_t sn = (uint32_t)std::floor(std::sqrt((double)o.num_samples));
+    if (sn == 0 || width == 0 || height == 0) {
+        std::fprintf(stderr, "Error: nothing to render (num-samples, width and height must be positive)\n");
+        return 1;
+    }
+    // The reference seeds from OS entropy without --seed; any fixed default is as good, and reproducible.
+    const uint64_t seed = o.has_seed ? o.seed : 0x5eed5eedull;
+
+    std::vector<std::vector<float>> parts((size_t)o.gpus, std::vector<float>(3 * width * height));
+    std::vector<rt_stats> stats((size_t)o.gpus);
+    std::vector<int> rc((size_t)o.gpus, 0);
+    std::vector<std::string> errs((size_t)o.gpus);
+    std::vector<std::thread> pool;
+    for (int g = 0; g < o.gpus; ++g) {
+        pool.emplace_back([&, g]() {
+            rt_render_params p{};
+            p.width = (uint32_t)width, p.height = (uint32_t)height, p.sn = sn, p.max_depth = max_depth;
+            p.seed = seed, p.stratum_begin = (uint32_t)g, p.stratum_step = (uint32_t)o.gpus, p.kernel = o.kernel;
+            rc[(size_t)g] = rt_render(scenes[(size_t)g], &p, parts[(size_t)g].data(), &stats[(size_t)g]);
+            if (rc[(size_t)g]) errs[(size_t)g] = rt_last_error();
+        });
+    }
+    for (auto& th : pool) th.join();
+    for (int g = 0; g < o.gpus; ++g)
+        if (rc[(size_t)g]) {
+            std::fprintf(stderr, "Error: render on GPU %d: %s\n", g, errs[(size_t)g].c_str());
+            return 1;
+        }
+    std::vector<float>& sum = parts[0];
+    for (int g = 1; g < o.gpus; ++g)
+        for (size_t i = 0; i < sum.size(); ++i) sum[i] += parts[(size_t)g][i];
+
+    std::vector<uint8_t> rgb(3 * width * height);
+    if (rt_tonemap_rgb8(sum.data(), (uint32_t)width, (uint32_t)height, (uint64_t)sn * sn, rgb.data())) return die("tonemap");
+
+    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    const double rays = (double)width * (double)height * (double)sn * (double)sn;  // primary samples, main.rs:188
+    std::fprintf(stderr, "\nDone in %.2fs (%.0f rays/s)\n", elapsed, rays / elapsed);  // main.rs:190
+    if (rt_write_png(o.output.c_str(), rgb.data(), (uint32_t)width, (uint32_t)height)) return die("could not write image");
+    if (o.json) {
+        double kernel_ms = 0;
+        for (auto& s : stats) kernel_ms = std::fmax(kernel_ms, s.kernel_ms);
+        std::printf("{\"samples\": %.0f, \"wall_s\": %.4f, \"kernel_ms\": %.3f, \"msamples_per_s\": %.3f, \"gpus\": %d}\n",
+                    rays, elapsed, kernel_ms, rays / (kernel_ms * 1e3), o.gpus);
+    }
+    for (rt_scene* s : scenes) rt_scene_destroy(s);
+    rt_scene_desc_free(desc);
+    return 0;
+}

@@ -1,0 +1,565 @@
+// C ABI (include/rt.h): scene flattening + upload, kernel launches, error plumbing.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt.h"
+#include "../host/bvh_build.h"
+#include "../host/scene_host.h"
+#include "device_scene.h"
+#include "kernels.h"
+#include "wavefront.h"
+
+namespace rt {
+extern int g_verbose;
+void write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t width, uint32_t height);
+}  // namespace rt
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int set_error(const std::string& m) {
+    g_last_error = m;
+    return 1;
+}
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                           std::to_string(__LINE__) + ")");                                               \
+    } while (0)
+
+float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+float int_bits(int32_t v) {
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+float uint_bits(uint32_t v) {
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+
+}  // namespace
+
+struct rt_scene {
+    int device = -1;  // RT_DEVICE_NONE: host-only
+    Bvh bvh;
+    rt_scene_info info{};
+    uint32_t stack_depth = 0;  // depth of the flattened tree incl. a synthetic root
+    DevScene dev{};
+    std::vector<void*> allocations;
+    DevCounters* d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::unique_ptr<WavefrontState> wf;
+
+    // flattened host copies (kept for host-only inspection and tests)
+    std::vector<float4> nodes, prims, tri_shade, materials;
+    std::vector<double> spheres, quads;
+    std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
+    std::vector<Node64> nodes64;
+    std::vector<Prim64> prims64;
+
+    ~rt_scene() {
+        if (device >= 0) {
+            int prev = 0;
+            if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess) {
+                wf.reset();
+                for (void* p : allocations) (void)hipFree(p);
+                if (ev0) (void)hipEventDestroy(ev0);
+                if (ev1) (void)hipEventDestroy(ev1);
+                (void)hipSetDevice(prev);
+            }
+        }
+    }
+};
+
+namespace {
+
+template <typename T>
+const T* upload(rt_scene& s, const std::vector<T>& v) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_CHECK(hipMalloc(&p, bytes));
+    s.allocations.push_back(p);
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    s.info.device_bytes += bytes;
+    return (const T*)p;
+}
+
+void validate(const rt_scene_desc& d) {
+    if (d.n_surfaces == 0) throw std::runtime_error("scene is empty");
+    if (d.n_surfaces >= (1u << 28)) throw std::runtime_error("too many surfaces");
+    auto check_mat = [&](int32_t m) {
+        if (m < 0 || (size_t)m >= d.n_materials) throw std::runtime_error("material index out of range");
+    };
+    for (size_t i = 0; i < d.n_materials; ++i)
+        if (d.materials[i].kind < 0 || d.materials[i].kind > 3) throw std::runtime_error("unknown material kind");
+    for (size_t i = 0; i < d.n_spheres; ++i) check_mat(d.spheres[i].material);
+    for (size_t i = 0; i < d.n_triangles; ++i) check_mat(d.triangles[i].material);
+    for (size_t i = 0; i < d.n_quads; ++i) check_mat(d.quads[i].material);
+    for (size_t i = 0; i < d.n_surfaces; ++i) {
+        const rt_surface_ref& s = d.surfaces[i];
+        size_t n = s.type == RT_SURF_SPHERE ? d.n_spheres
+                   : s.type == RT_SURF_TRIANGLE ? d.n_triangles
+                   : s.type == RT_SURF_QUAD ? d.n_quads
+                                            : 0;
+        if (s.index < 0 || (size_t)s.index >= n) throw std::runtime_error("surface reference out of range");
+    }
+}
+
+// Tree -> linear arrays.  Inner nodes keep their children's boxes (one fetch decides both children);
+// leaves become runs of slots in the in-order sequence, closed by a last-in-leaf flag.
+void flatten(const rt_scene_desc& d, rt_scene& s) {
+    const Bvh& bvh = s.bvh;
+    const size_t n_surf = d.n_surfaces;
+    const bool root_is_leaf = bvh.nodes[0].is_leaf();
+    const size_t n_slots = n_surf + (root_is_leaf ? 1 : 0);
+
+    // f32 boxes must stay conservative under the fma slab form lo*inv_d - o*inv_d, whose rounding error in
+    // position space is about |o| * 2^-24: inflate every box by the scene's largest coordinate * 2^-22.
+    double maxabs = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        maxabs = std::fmax(maxabs, std::fabs(bvh.nodes[0].box.lo.get(a)));
+        maxabs = std::fmax(maxabs, std::fabs(bvh.nodes[0].box.hi.get(a)));
+        maxabs = std::fmax(maxabs, std::fabs(d.camera.origin[a]));
+    }
+    const double inflate = maxabs * 0x1p-22;
+
+    std::vector<int32_t> inner_id(bvh.nodes.size(), -1);
+    int32_t n_inner = 0;
+    for (size_t i = 0; i < bvh.nodes.size(); ++i)
+        if (!bvh.nodes[i].is_leaf()) inner_id[i] = n_inner++;
+    auto child_ref = [&](int32_t node) -> int32_t {
+        const BvhNode& n = bvh.nodes[node];
+        return n.is_leaf() ? ~n.first : inner_id[node];
+    };
+
+    const size_t n_dev_nodes = root_is_leaf ? 1 : (size_t)n_inner;
+    s.nodes.assign(4 * n_dev_nodes, float4{0, 0, 0, 0});
+    s.nodes64.assign(n_dev_nodes, Node64{});
+    auto put_child = [&](size_t node, int c, const Aabb& b, int32_t ref) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = round_down(b.lo.get(a) - inflate);
+            hi[a] = round_up(b.hi.get(a) + inflate);
+            s.nodes64[node].lo[c][a] = b.lo.get(a);
+            s.nodes64[node].hi[c][a] = b.hi.get(a);
+        }
+        s.nodes64[node].child[c] = ref;
+        float4* n = &s.nodes[4 * node];
+        if (c == 0) {
+            n[0] = {lo[0], lo[1], lo[2], hi[0]};
+            n[1].x = hi[1], n[1].y = hi[2];
+            n[3].x = int_bits(ref);
+        } else {
+            n[1].z = lo[0], n[1].w = lo[1];
+            n[2] = {lo[2], hi[0], hi[1], hi[2]};
+            n[3].y = int_bits(ref);
+        }
+    };
+    if (root_is_leaf) {
+        // synthetic root: child 0 = the leaf; child 1 = a far-away point box over one dummy slot that
+        // can never be hit (the f64 kernel skips it via kNoChild)
+        put_child(0, 0, bvh.nodes[0].box, ~0);
+        Aabb far{{1e30, 1e30, 1e30}, {1e30, 1e30, 1e30}};
+        put_child(0, 1, far, ~(int32_t)n_surf);
+        s.nodes64[0].child[1] = kNoChild;
+        s.stack_depth = 2;
+    } else {
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+            const BvhNode& n = bvh.nodes[i];
+            if (n.is_leaf()) continue;
+            put_child(inner_id[i], 0, bvh.nodes[n.left].box, child_ref(n.left));
+            put_child(inner_id[i], 1, bvh.nodes[n.right].box, child_ref(n.right));
+        }
+        s.stack_depth = bvh.max_depth;
+    }
+
+    // leaf slots
+    std::vector<uint8_t> last(n_slots, 0);
+    for (const BvhNode& n : bvh.nodes)
+        if (n.is_leaf() && n.count > 0) last[n.first + n.count - 1] = 1;
+    s.prims.assign(3 * n_slots, float4{0, 0, 0, 0});
+    s.tri_shade.assign(3 * n_slots, float4{0, 0, 0, 0});
+    s.prims64.assign(n_slots, Prim64{});
+    s.slot_surface.assign(n_slots, -1);
+    for (size_t slot = 0; slot < n_surf; ++slot) {
+        const int32_t sid = bvh.order[slot];
+        const rt_surface_ref& ref = d.surfaces[sid];
+        s.slot_surface[slot] = sid;
+        Prim64& p64 = s.prims64[slot];
+        p64.type = ref.type, p64.last = last[slot], p64.surface = sid;
+        uint32_t meta = (uint32_t)ref.type | (last[slot] ? kMetaLast : 0u);
+        float4* p = &s.prims[3 * slot];
+        if (ref.type == RT_SURF_TRIANGLE) {
+            const rt_triangle& t = d.triangles[ref.index];
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) p64.a[3 * k + a] = t.v[k][a];
+            p[0] = {(float)t.v[0][0], (float)t.v[0][1], (float)t.v[0][2], uint_bits(meta)};
+            p[1] = {(float)(t.v[1][0] - t.v[0][0]), (float)(t.v[1][1] - t.v[0][1]), (float)(t.v[1][2] - t.v[0][2]), 0};
+            p[2] = {(float)(t.v[2][0] - t.v[0][0]), (float)(t.v[2][1] - t.v[0][1]), (float)(t.v[2][2] - t.v[0][2]), 0};
+            float4* sh = &s.tri_shade[3 * slot];
+            for (int k = 0; k < 3; ++k) sh[k] = {(float)t.n[k][0], (float)t.n[k][1], (float)t.n[k][2], 0};
+            sh[0].w = int_bits(t.material);
+        } else if (ref.type == RT_SURF_SPHERE) {
+            const rt_sphere& sp = d.spheres[ref.index];
+            for (int a = 0; a < 3; ++a) p64.a[a] = sp.center[a];
+            p64.a[3] = sp.radius;
+            meta |= (uint32_t)ref.index << kMetaIndexShift;
+            p[0].w = uint_bits(meta);
+        } else {
+            const rt_quad& q = d.quads[ref.index];
+            for (int a = 0; a < 3; ++a) {
+                p64.a[a] = q.normal[a], p64.a[4 + a] = q.q[a], p64.a[7 + a] = q.u[a];
+                p64.a[10 + a] = q.v[a], p64.a[13 + a] = q.w[a];
+            }
+            p64.a[3] = q.d;
+            meta |= (uint32_t)ref.index << kMetaIndexShift;
+            p[0].w = uint_bits(meta);
+        }
+    }
+    if (root_is_leaf) {  // the dummy slot: a degenerate triangle (det == 0 -> never hit)
+        s.prims[3 * n_surf].w = uint_bits(1u | kMetaLast);
+        s.prims64[n_surf].type = 1, s.prims64[n_surf].last = 1, s.prims64[n_surf].surface = -1;
+    }
+
+    s.spheres.resize(4 * d.n_spheres);
+    s.sphere_mat.resize(d.n_spheres);
+    for (size_t i = 0; i < d.n_spheres; ++i) {
+        for (int a = 0; a < 3; ++a) s.spheres[4 * i + a] = d.spheres[i].center[a];
+        s.spheres[4 * i + 3] = d.spheres[i].radius;
+        s.sphere_mat[i] = d.spheres[i].material;
+    }
+    s.quads.assign(16 * d.n_quads, 0.0);
+    s.quad_mat.resize(d.n_quads);
+    for (size_t i = 0; i < d.n_quads; ++i) {
+        const rt_quad& q = d.quads[i];
+        V3 u{q.u[0], q.u[1], q.u[2]}, v{q.v[0], q.v[1], q.v[2]}, w{q.w[0], q.w[1], q.w[2]};
+        V3 A = cross(v, w), B = cross(w, u);  // w·(p×v) = p·(v×w), w·(u×p) = p·(w×u)
+        double* o = &s.quads[16 * i];
+        for (int a = 0; a < 3; ++a) o[a] = q.normal[a], o[4 + a] = q.q[a];
+        o[3] = q.d;
+        o[7] = A.x, o[8] = A.y, o[9] = A.z, o[10] = B.x, o[11] = B.y, o[12] = B.z;
+        s.quad_mat[i] = q.material;
+    }
+    s.materials.resize(d.n_materials);
+    s.mat_kind.resize(d.n_materials);
+    for (size_t i = 0; i < d.n_materials; ++i) {
+        const rt_material& m = d.materials[i];
+        s.materials[i] = {(float)m.albedo[0], (float)m.albedo[1], (float)m.albedo[2], (float)m.param};
+        s.mat_kind[i] = m.kind;
+    }
+
+    s.info.n_surfaces = n_surf;
+    s.info.n_nodes = bvh.nodes.size();
+    s.info.n_leaves = bvh.n_leaves;
+    s.info.max_depth = bvh.max_depth;
+    s.info.max_leaf_size = bvh.max_leaf_size;
+}
+
+void fill_camera(const rt_scene_desc& d, DevScene& dev) {
+    const rt_camera& c = d.camera;
+    for (int a = 0; a < 3; ++a) {
+        dev.cam.origin[a] = c.origin[a];
+        dev.cam.ll_rel[a] = (float)(c.lower_left[a] - c.origin[a]);
+        dev.cam.u[a] = (float)c.u[a];
+        dev.cam.v[a] = (float)c.v[a];
+        dev.cam64[0][a] = c.origin[a], dev.cam64[1][a] = c.lower_left[a];
+        dev.cam64[2][a] = c.horizontal[a], dev.cam64[3][a] = c.vertical[a];
+        dev.background[a] = (float)d.background[a];
+    }
+    dev.cam.lens_radius = (float)c.lens_radius;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    explicit DeviceGuard(int device) {
+        if (device < 0) return;
+        HIP_CHECK(hipGetDevice(&prev));
+        if (prev != device) {
+            HIP_CHECK(hipSetDevice(device));
+            active = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (active) (void)hipSetDevice(prev);
+    }
+};
+
+DevRenderParams make_params(const rt_scene& s, const rt_render_params& p) {
+    if (p.width == 0 || p.height == 0) throw std::runtime_error("width and height must be positive");
+    if ((uint64_t)p.width * p.height >= (1ull << 31)) throw std::runtime_error("image too large");
+    if (p.sn == 0 || p.sn > 65535) throw std::runtime_error("sn must be in [1, 65535]");
+    if (p.max_depth == 0) throw std::runtime_error("max_depth must be positive");
+    if (s.device < 0) throw std::runtime_error("scene was created host-only (no device): cannot render");
+    DevRenderParams rp{};
+    rp.width = p.width, rp.height = p.height, rp.sn = p.sn, rp.max_depth = p.max_depth;
+    rp.n_strata = p.sn * p.sn;
+    rp.stratum_begin = p.stratum_begin;
+    rp.stratum_step = p.stratum_step ? p.stratum_step : 1;
+    rp.seed_lo = (uint32_t)p.seed, rp.seed_hi = (uint32_t)(p.seed >> 32);
+    rp.recip_sn = (float)(1.0 / (double)p.sn);
+    return rp;
+}
+
+}  // namespace
+
+// hor_px / ver_px depend on the image size, so they are filled per call from the f64 camera.
+static void camera_for_size(const rt_scene& s, uint32_t width, uint32_t height, DevScene& dev) {
+    dev = s.dev;
+    for (int a = 0; a < 3; ++a) {
+        dev.cam.hor_px[a] = (float)(s.dev.cam64[2][a] / (double)width);
+        dev.cam.ver_px[a] = (float)(s.dev.cam64[3][a] / (double)height);
+    }
+}
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+const char* rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }
+void rt_set_verbose(int v) { rt::g_verbose = v; }
+
+int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_scene_desc** out) {
+    if (!yaml_path || !out) return set_error("rt_load_scene: null argument");
+    try {
+        auto hs = std::make_unique<HostScene>();
+        load_scene_file(yaml_path, aspect_ratio, use_bvh != 0, *hs);
+        *out = &hs.release()->desc;
+        return 0;
+    } catch (const std::exception& e) {
+        return set_error(std::string("load scene file '") + yaml_path + "': " + e.what());
+    }
+}
+
+void rt_scene_desc_free(rt_scene_desc* desc) {
+    if (desc) delete reinterpret_cast<HostScene*>(desc);
+}
+
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+    if (!desc || !out) return set_error("rt_scene_create: null argument");
+    try {
+        validate(*desc);
+        auto s = std::make_unique<rt_scene>();
+        auto t0 = std::chrono::steady_clock::now();
+        build_bvh(*desc, s->bvh);
+        flatten(*desc, *s);
+        s->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (s->stack_depth > 64)
+            throw std::runtime_error("BVH depth " + std::to_string(s->stack_depth) +
+                                     " exceeds the traversal stack (64 levels)");
+        fill_camera(*desc, s->dev);
+        s->dev.n_slots = (uint32_t)s->slot_surface.size();
+        if (device == RT_DEVICE_NONE) {
+            s->device = -1;
+            *out = s.release();
+            return 0;
+        }
+        if (device < 0) HIP_CHECK(hipGetDevice(&device));
+        s->device = device;
+        DeviceGuard guard(device);
+        s->dev.nodes = upload(*s, s->nodes);
+        s->dev.prims = upload(*s, s->prims);
+        s->dev.tri_shade = upload(*s, s->tri_shade);
+        s->dev.spheres = upload(*s, s->spheres);
+        s->dev.quads = upload(*s, s->quads);
+        s->dev.sphere_mat = upload(*s, s->sphere_mat);
+        s->dev.quad_mat = upload(*s, s->quad_mat);
+        s->dev.materials = upload(*s, s->materials);
+        s->dev.mat_kind = upload(*s, s->mat_kind);
+        s->dev.slot_surface = upload(*s, s->slot_surface);
+        s->dev.nodes64 = upload(*s, s->nodes64);
+        s->dev.prims64 = upload(*s, s->prims64);
+        std::vector<DevCounters> zero(1);
+        s->d_counters = const_cast<DevCounters*>(upload(*s, zero));
+        HIP_CHECK(hipEventCreate(&s->ev0));
+        HIP_CHECK(hipEventCreate(&s->ev1));
+        *out = s.release();
+        return 0;
+    } catch (const std::exception& e) {
+        return set_error(std::string("rt_scene_create: ") + e.what());
+    }
+}
+
+void rt_scene_destroy(rt_scene* scene) { delete scene; }
+
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* info) {
+    if (!scene || !info) return set_error("rt_scene_get_info: null argument");
+    *info = scene->info;
+    return 0;
+}
+
+int rt_scene_leaf_order(const rt_scene* scene, int32_t* out_surface_ids) {
+    if (!scene || !out_surface_ids) return set_error("rt_scene_leaf_order: null argument");
+    std::memcpy(out_surface_ids, scene->bvh.order.data(), scene->bvh.order.size() * sizeof(int32_t));
+    return 0;
+}
+
+int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream_v,
+                     rt_stats* stats) {
+    if (!scene || !params || !d_rgb_sum) return set_error("rt_render_device: null argument");
+    try {
+        DevRenderParams rp = make_params(*scene, *params);
+        DeviceGuard guard(scene->device);
+        hipStream_t stream = (hipStream_t)stream_v;
+        DevScene dev;
+        camera_for_size(*scene, rp.width, rp.height, dev);
+        const bool count = stats && params->collect_stats;
+        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, sizeof(DevCounters), stream));
+        if (stats) HIP_CHECK(hipEventRecord(scene->ev0, stream));
+        uint32_t n_launches = 1;
+        if (params->kernel == RT_KERNEL_PERSISTENT) {
+            HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, d_rgb_sum, scene->d_counters, count, stream));
+        } else if (params->kernel == RT_KERNEL_WAVEFRONT) {
+            if (!scene->wf) scene->wf = std::make_unique<WavefrontState>();
+            HIP_CHECK(render_wavefront(*scene->wf, dev, rp, scene->stack_depth, d_rgb_sum, scene->d_counters, count,
+                                       stream, &n_launches));
+        } else {
+            throw std::runtime_error("unknown kernel selector " + std::to_string(params->kernel));
+        }
+        if (stats) {
+            HIP_CHECK(hipEventRecord(scene->ev1, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            std::memset(stats, 0, sizeof *stats);
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+            stats->kernel_ms = ms;
+            stats->n_launches = n_launches;
+            const uint64_t mine =
+                rp.stratum_begin >= rp.n_strata ? 0 : (rp.n_strata - rp.stratum_begin + rp.stratum_step - 1) / rp.stratum_step;
+            stats->samples = (uint64_t)rp.width * rp.height * mine;
+            if (count) {
+                DevCounters c;
+                HIP_CHECK(hipMemcpy(&c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+                stats->segments = c.segments, stats->node_visits = c.node_visits, stats->tri_tests = c.tri_tests;
+                stats->sphere_tests = c.sphere_tests, stats->quad_tests = c.quad_tests;
+            }
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        return set_error(std::string("rt_render_device: ") + e.what());
+    }
+}
+
+int rt_render(rt_scene* scene, const rt_render_params* params, float* rgb_sum, rt_stats* stats) {
+    if (!scene || !params || !rgb_sum) return set_error("rt_render: null argument");
+    float* d = nullptr;
+    try {
+        if (scene->device < 0) throw std::runtime_error("scene was created host-only (no device): cannot render");
+        DeviceGuard guard(scene->device);
+        const size_t bytes = (size_t)3 * params->width * params->height * sizeof(float);
+        HIP_CHECK(hipMalloc((void**)&d, bytes));
+        rt_stats local;
+        int rc = rt_render_device(scene, params, d, nullptr, stats ? stats : &local);
+        if (rc == 0) HIP_CHECK(hipMemcpy(rgb_sum, d, bytes, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        return rc;
+    } catch (const std::exception& e) {
+        if (d) (void)hipFree(d);
+        return set_error(std::string("rt_render: ") + e.what());
+    }
+}
+
+int rt_primary_hits(rt_scene* scene, uint32_t width, uint32_t height, int precision, int32_t* prim_id, double* t) {
+    if (!scene || !prim_id || !t) return set_error("rt_primary_hits: null argument");
+    int32_t* d_id = nullptr;
+    double* d_t = nullptr;
+    try {
+        if (scene->device < 0) throw std::runtime_error("scene was created host-only (no device)");
+        if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 31))
+            throw std::runtime_error("bad image size");
+        if (precision != 32 && precision != 64) throw std::runtime_error("precision must be 32 or 64");
+        DeviceGuard guard(scene->device);
+        const size_t n = (size_t)width * height;
+        HIP_CHECK(hipMalloc((void**)&d_id, n * sizeof(int32_t)));
+        HIP_CHECK(hipMalloc((void**)&d_t, n * sizeof(double)));
+        DevScene dev;
+        camera_for_size(*scene, width, height, dev);
+        if (precision == 64)
+            HIP_CHECK(launch_primary64(dev, width, height, d_id, d_t, nullptr));
+        else
+            HIP_CHECK(launch_primary32(dev, width, height, scene->stack_depth, d_id, d_t, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(prim_id, d_id, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(d_id), (void)hipFree(d_t);
+        return 0;
+    } catch (const std::exception& e) {
+        if (d_id) (void)hipFree(d_id);
+        if (d_t) (void)hipFree(d_t);
+        return set_error(std::string("rt_primary_hits: ") + e.what());
+    }
+}
+
+int rt_tonemap_rgb8_device(const float* d_rgb_sum, uint32_t width, uint32_t height, uint64_t n_samples,
+                           uint8_t* d_out, void* stream) {
+    if (!d_rgb_sum || !d_out) return set_error("rt_tonemap_rgb8_device: null argument");
+    if (n_samples == 0) return set_error("rt_tonemap_rgb8_device: n_samples must be positive");
+    try {
+        HIP_CHECK(launch_tonemap(d_rgb_sum, 3u * width * height, (double)n_samples, d_out, (hipStream_t)stream));
+        return 0;
+    } catch (const std::exception& e) {
+        return set_error(std::string("rt_tonemap_rgb8_device: ") + e.what());
+    }
+}
+
+int rt_tonemap_rgb8(const float* rgb_sum, uint32_t width, uint32_t height, uint64_t n_samples, uint8_t* out) {
+    if (!rgb_sum || !out) return set_error("rt_tonemap_rgb8: null argument");
+    float* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    try {
+        const size_t n = (size_t)3 * width * height;
+        HIP_CHECK(hipMalloc((void**)&d_in, n * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&d_out, n));
+        HIP_CHECK(hipMemcpy(d_in, rgb_sum, n * sizeof(float), hipMemcpyHostToDevice));
+        int rc = rt_tonemap_rgb8_device(d_in, width, height, n_samples, d_out, nullptr);
+        if (rc == 0) {
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost));
+        }
+        (void)hipFree(d_in), (void)hipFree(d_out);
+        return rc;
+    } catch (const std::exception& e) {
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        return set_error(std::string("rt_tonemap_rgb8: ") + e.what());
+    }
+}
+
+int rt_write_png(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb) return set_error("rt_write_png: null argument");
+    try {
+        write_png_rgb8(path, rgb, width, height);
+        return 0;
+    } catch (const std::exception& e) {
+        return set_error(e.what());
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,361 @@
+// Device functions shared by the persistent and the wavefront render kernels (gfx950, wave64).
+//   sampling     main.rs:165-173, camera.rs:76-87, util.rs:15-35
+//   traversal    bvh.rs:262-314 re-ordered near-child-first with interval narrowing; equal-t ties go to the
+//                higher in-order leaf slot, which is what the reference's recursion yields
+//   intersection surfaces.rs:73-106 (sphere), 246-279 (triangle), 330-354 (quad)
+//   shading      scene/mod.rs:86-135, material.rs:99-181
+// Triangles and boxes are f32; the few spheres/quads of a scene are intersected in f64 from an f64 ray
+// origin (radius-1000 ground spheres and 555-unit Cornell walls are where f32 self-intersection fails).
+#pragma once
+#include "device_scene.h"
+
+namespace rt {
+
+// ---------------------------------------------------------------- RNG
+// Counter-seeded PCG-XSH-RR 64/32: one stream per (seed, pixel, stratum), so an image does not depend on
+// how strata are sharded over GPUs or how lanes are scheduled.  24-bit uniforms are exact in f32 AND f64,
+// so the f64 oracle draws the very same variates (oracle/rt_ref.cpp restates this).
+struct Rng {
+    uint64_t s;
+};
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ void rng_init(Rng& r, uint64_t seed, uint32_t pixel, uint32_t stratum) {
+    r.s = splitmix64(seed ^ splitmix64(((uint64_t)pixel << 32) | stratum));
+}
+__device__ __forceinline__ uint32_t rng_next(Rng& r) {
+    uint64_t old = r.s;
+    r.s = old * 6364136223846793005ull + 1442695040888963407ull;
+    uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+    uint32_t rot = (uint32_t)(old >> 59);
+    return (xs >> rot) | (xs << ((32u - rot) & 31u));
+}
+__device__ __forceinline__ float rng_u01(Rng& r) { return (float)(rng_next(r) >> 8) * 0x1p-24f; }  // [0,1)
+__device__ __forceinline__ float rng_pm1(Rng& r) { return rng_u01(r) * 2.0f - 1.0f; }              // [-1,1), exact
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ F3 f3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ F3 f3(float4 v) { return {v.x, v.y, v.z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(float c, F3 v) { return {c * v.x, c * v.y, c * v.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ F3 neg(F3 a) { return {-a.x, -a.y, -a.z}; }
+
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 d3(const double* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ D3 d3(F3 v) { return {(double)v.x, (double)v.y, (double)v.z}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator*(double c, D3 v) { return {c * v.x, c * v.y, c * v.z}; }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ F3 tof(D3 v) { return {(float)v.x, (float)v.y, (float)v.z}; }
+
+// util.rs:15-24 / 26-35 — rejection sampling, same draw order as the reference.
+__device__ __forceinline__ F3 rng_in_unit_sphere(Rng& r) {
+    while (true) {
+        float x = rng_pm1(r), y = rng_pm1(r), z = rng_pm1(r);
+        if (x * x + y * y + z * z < 1.0f) return {x, y, z};
+    }
+}
+__device__ __forceinline__ void rng_in_unit_disk(Rng& r, float& x, float& y) {
+    while (true) {
+        x = rng_pm1(r), y = rng_pm1(r);
+        if (x * x + y * y < 1.0f) return;
+    }
+}
+
+// ---------------------------------------------------------------- ray state
+struct Ray {
+    D3 o;  // f64 origin: exact input of the sphere/quad tests and of o + t*d
+    F3 d;  // direction, NOT normalised (camera.rs:84, material.rs:110)
+};
+
+struct HitRec {
+    float t;
+    int slot;      // leaf slot of the closest hit, -1 = miss
+    float bu, bv;  // triangle barycentrics
+};
+
+struct TraceStats {
+    uint32_t nodes = 0, tris = 0, spheres = 0, quads = 0;
+};
+
+// Camera ray for (pixel, stratum): main.rs:157-174 + camera.rs:76-87.
+__device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
+                                          uint32_t stratum, Rng& rng) {
+    uint32_t si = stratum / rp.sn, sj = stratum - si * rp.sn;
+    float ju = -0.5f + rp.recip_sn * ((float)si + rng_u01(rng));
+    float jv = -0.5f + rp.recip_sn * ((float)sj + rng_u01(rng));
+    float s = (float)(pi + 1) + ju;  // in pixel units; *hor_px == (centeru + jitteru*pixel_du)*horizontal
+    float t = (float)(pj + 1) + jv;
+    float rx, ry;
+    rng_in_unit_disk(rng, rx, ry);  // always drawn, even for a pinhole (camera.rs:77)
+    rx *= sc.cam.lens_radius, ry *= sc.cam.lens_radius;
+    (void)rng_u01(rng);  // shutter time: drawn (camera.rs:80), without effect on stationary scenes
+    F3 off = rx * f3(sc.cam.u) + ry * f3(sc.cam.v);
+    Ray ray;
+    ray.o = d3(sc.cam.origin) - d3(off);
+    ray.d = f3(sc.cam.ll_rel) + s * f3(sc.cam.hor_px) + t * f3(sc.cam.ver_px) + off;
+    return ray;
+}
+
+// ---------------------------------------------------------------- primitive tests
+// Sphere, f64 (surfaces.rs:73-106).  Returns the first root inside [tmin, tmax], or -1.
+__device__ __forceinline__ double sphere_root(const double* sp, D3 o, D3 d, double tmin, double tmax) {
+    D3 oc = o - d3(sp);
+    double r = sp[3];
+    double a = dot(d, d);
+    double half_b = dot(oc, d);
+    double c = dot(oc, oc) - r * r;
+    double disc = half_b * half_b - a * c;
+    if (disc > 0.0) {
+        double root = sqrt(disc);
+        double t0 = (-half_b - root) / a;
+        if (tmin <= t0 && t0 <= tmax) return t0;
+        double t1 = (-half_b + root) / a;
+        if (tmin <= t1 && t1 <= tmax) return t1;
+    }
+    return -1.0;
+}
+
+// Quad, f64 (surfaces.rs:330-354).  alpha = w·(p×v) = p·(v×w), beta = w·(u×p) = p·(w×u).
+__device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double tmin, double tmax) {
+    D3 n = d3(q);
+    double denom = dot(n, d);
+    if (fabs(denom) < 1e-8) return -1.0;
+    double t = (q[3] - dot(n, o)) / denom;
+    if (t < 1e-4 || !(tmin <= t && t <= tmax)) return -1.0;
+    D3 p = (o + t * d) - d3(q + 4);
+    double alpha = dot(p, d3(q + 7));
+    double beta = dot(p, d3(q + 10));
+    if (!(0.0 <= alpha && alpha < 1.0 && 0.0 <= beta && beta < 1.0)) return -1.0;
+    return t;
+}
+
+// ---------------------------------------------------------------- traversal
+// `stack` points at this lane's column of an LDS array laid out [level][lane] (stride = block size), so
+// a push/pop is one conflict-free ds_write/ds_read.  The host checks tree depth <= stack levels.
+template <bool STATS>
+__device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& ray, float tmin, int* stack,
+                                                int stack_stride, TraceStats& st) {
+    const F3 o = tof(ray.o);
+    const F3 d = ray.d;
+    const float idx = __builtin_amdgcn_rcpf(d.x), idy = __builtin_amdgcn_rcpf(d.y), idz = __builtin_amdgcn_rcpf(d.z);
+    const float oodx = o.x * idx, oody = o.y * idy, oodz = o.z * idz;
+
+    HitRec best;
+    best.t = __builtin_inff();
+    best.slot = -1;
+    best.bu = best.bv = 0.f;
+
+    int sp = 0;
+    int node = 0;  // root is always an inner node (a single-leaf tree gets a synthetic root)
+    while (true) {
+        // ---- descend through inner nodes
+        while (node >= 0) {
+            if (STATS) st.nodes++;
+            const float4 n0 = sc.nodes[4 * node + 0];
+            const float4 n1 = sc.nodes[4 * node + 1];
+            const float4 n2 = sc.nodes[4 * node + 2];
+            const float4 n3 = sc.nodes[4 * node + 3];
+            // child 0: lo = (n0.x n0.y n0.z) hi = (n0.w n1.x n1.y); child 1: lo = (n1.z n1.w n2.x) hi = (n2.y n2.z n2.w)
+            const float tmax_pad = best.t * 1.0000004f;
+            float ax = fmaf(n0.x, idx, -oodx), bx = fmaf(n0.w, idx, -oodx);
+            float ay = fmaf(n0.y, idy, -oody), by = fmaf(n1.x, idy, -oody);
+            float az = fmaf(n0.z, idz, -oodz), bz = fmaf(n1.y, idz, -oodz);
+            float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+            float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
+            ax = fmaf(n1.z, idx, -oodx), bx = fmaf(n2.y, idx, -oodx);
+            ay = fmaf(n1.w, idy, -oody), by = fmaf(n2.z, idy, -oody);
+            az = fmaf(n2.x, idz, -oodz), bz = fmaf(n2.w, idz, -oodz);
+            float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+            float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
+            const bool h0 = t0n <= t0f, h1 = t1n <= t1f;
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                const bool swap = t1n < t0n;
+                const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                stack[sp * stack_stride] = farc;
+                ++sp;
+                node = nearc;
+            } else if (h0) {
+                node = c0;
+            } else if (h1) {
+                node = c1;
+            } else {
+                if (sp == 0) return best;
+                --sp;
+                node = stack[sp * stack_stride];
+            }
+        }
+        // ---- leaf: scan slots until the last-in-leaf flag (bvh.rs:300-314)
+        if (node != kNoChild) {
+            int slot = ~node;
+            while (true) {
+                const float4 p0 = sc.prims[3 * slot + 0];
+                const uint32_t meta = __float_as_uint(p0.w);
+                const uint32_t type = meta & kMetaTypeMask;
+                float t = -1.f, bu = 0.f, bv = 0.f;
+                if (type == 1u) {  // triangle, Möller–Trumbore with host-precomputed edges
+                    if (STATS) st.tris++;
+                    const float4 p1 = sc.prims[3 * slot + 1];
+                    const float4 p2 = sc.prims[3 * slot + 2];
+                    const F3 e1 = f3(p1), e2 = f3(p2);
+                    const F3 pvec = cross(d, e2);
+                    const float det = dot(e1, pvec);
+                    if (!(-1e-8f < det && det < 1e-8f)) {
+                        const float inv_det = __builtin_amdgcn_rcpf(det);
+                        const F3 tvec = o - f3(p0);
+                        const float u = dot(tvec, pvec) * inv_det;
+                        if (u >= 0.f && u <= 1.f) {
+                            const F3 qvec = cross(tvec, e1);
+                            const float v = dot(d, qvec) * inv_det;
+                            if (!(v < 0.f || u + v > 1.f)) {
+                                const float tt = dot(e2, qvec) * inv_det;
+                                if (!(tt < 1e-4f) && tmin <= tt) {
+                                    t = tt, bu = u, bv = v;
+                                }
+                            }
+                        }
+                    }
+                } else if (type == 0u) {
+                    if (STATS) st.spheres++;
+                    const double* spd = sc.spheres + 4 * (meta >> kMetaIndexShift);
+                    t = (float)sphere_root(spd, ray.o, d3(d), (double)tmin, (double)best.t);
+                } else {
+                    if (STATS) st.quads++;
+                    const double* qd = sc.quads + 16 * (meta >> kMetaIndexShift);
+                    t = (float)quad_root(qd, ray.o, d3(d), (double)tmin, (double)best.t);
+                }
+                // closest wins; an exact tie goes to the later slot of the in-order leaf sequence
+                if (t >= tmin && (t < best.t || (t == best.t && slot > best.slot))) {
+                    best.t = t, best.slot = slot, best.bu = bu, best.bv = bv;
+                }
+                if (meta & kMetaLast) break;
+                ++slot;
+            }
+        }
+        if (sp == 0) return best;
+        --sp;
+        node = stack[sp * stack_stride];
+    }
+}
+
+// ---------------------------------------------------------------- shading
+__device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (2.0f * dot(v, n)) * n; }  // material.rs:171-173
+
+// One bounce (one iteration of the loop at scene/mod.rs:103-125).  `lsum` gathers radiance in the forward
+// form  L += T*emitted; T *= albedo  (equal to resolve_color's back-to-front fold).  Returns whether the
+// path continues; `depth` follows the reference's counter including the metal re-sampling quirk (Q1).
+__device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const HitRec& hit, float tmin, Rng& rng,
+                                             F3& thr, F3& lsum, uint32_t& depth, uint32_t max_depth) {
+    if (hit.slot < 0) {  // escaped: (0, background), scene/mod.rs:122
+        lsum = lsum + thr * f3(sc.background);
+        return false;
+    }
+    const float4 p0 = sc.prims[3 * hit.slot];
+    const uint32_t meta = __float_as_uint(p0.w);
+    const uint32_t type = meta & kMetaTypeMask;
+    const D3 dd = d3(ray.d);
+    F3 n;
+    int mat;
+    D3 p;
+    if (type == 1u) {
+        const float4 s0 = sc.tri_shade[3 * hit.slot + 0];
+        const float4 s1 = sc.tri_shade[3 * hit.slot + 1];
+        const float4 s2 = sc.tri_shade[3 * hit.slot + 2];
+        // un-normalised barycentric blend (Q3), surfaces.rs:277
+        n = hit.bu * f3(s1) + hit.bv * f3(s2) + (1.0f - hit.bu - hit.bv) * f3(s0);
+        mat = __float_as_int(s0.w);
+        p = ray.o + (double)hit.t * dd;
+    } else if (type == 0u) {
+        const uint32_t i = meta >> kMetaIndexShift;
+        const double* spd = sc.spheres + 4 * i;
+        double t = sphere_root(spd, ray.o, dd, (double)tmin, __builtin_inf());
+        if (t < 0.0) t = (double)hit.t;
+        p = ray.o + t * dd;
+        D3 nn = (1.0 / spd[3]) * (p - d3(spd));  // signed radius: a negative one flips the normal
+        n = tof(nn);
+        mat = sc.sphere_mat[i];
+    } else {
+        const uint32_t i = meta >> kMetaIndexShift;
+        const double* qd = sc.quads + 16 * i;
+        double t = quad_root(qd, ray.o, dd, (double)tmin, __builtin_inf());
+        if (t < 0.0) t = (double)hit.t;
+        p = ray.o + t * dd;
+        n = tof(d3(qd));
+        mat = sc.quad_mat[i];
+    }
+    // Hit::new, trace.rs:59-76: front face from the (shading) normal (Q4)
+    const bool front = dot(ray.d, n) < 0.0f;
+    if (!front) n = neg(n);
+
+    const float4 m = sc.materials[mat];
+    const int kind = sc.mat_kind[mat];
+    const F3 albedo = f3(m);
+    if (kind == 3) {  // DiffuseLight: emits on both faces, never scatters (material.rs:66-72, 94)
+        lsum = lsum + thr * albedo;
+        return false;  // the reference re-traces this ray up to depth 40 to the same end (Q1)
+    }
+    F3 dir;
+    if (kind == 0) {  // Lambertian, material.rs:100-118
+        const F3 s = rng_in_unit_sphere(rng);
+        const float inv_len = 1.0f / sqrtf(dot(s, s));
+        dir = n + inv_len * s;
+        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
+    } else if (kind == 1) {  // Metal, material.rs:126-138 + the re-sampling loop of Q1
+        const F3 refl = reflect(ray.d, n);  // incoming direction not normalised (Q2)
+        while (true) {
+            const F3 s = rng_in_unit_sphere(rng);
+            dir = refl + m.w * s;
+            if (dot(dir, n) > 1e-8f) break;
+            // absorbed: nothing pushed, depth += 1, same ray re-traced to the same hit, fuzz re-drawn
+            if (++depth >= max_depth) return false;
+        }
+    } else {  // Dielectric, material.rs:141-181
+        const float ratio = front ? 1.0f / m.w : m.w;
+        const float inv_len = 1.0f / sqrtf(dot(ray.d, ray.d));
+        const F3 ud = inv_len * ray.d;
+        const float cos_theta = fminf(dot(neg(ud), n), 1.0f);
+        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool refl = ratio * sin_theta > 1.0f;
+        if (!refl) {  // short-circuit: the uniform is drawn only when refraction is possible
+            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            r0 = r0 * r0;
+            const float c1 = 1.0f - cos_theta;
+            const float c2 = c1 * c1;
+            refl = r0 + (1.0f - r0) * (c2 * c2 * c1) > rng_u01(rng);
+        }
+        if (refl) {
+            dir = reflect(ud, n);
+        } else {
+            const F3 perp = ratio * (ud + cos_theta * n);
+            const float par = -sqrtf(fabsf(1.0f - dot(perp, perp)));
+            dir = perp + par * n;
+        }
+    }
+    thr = thr * albedo;
+    ray.o = p;
+    ray.d = dir;
+    return ++depth < max_depth;
+}
+
+}  // namespace rt

@@ -1,0 +1,66 @@
+// Scene layout in HBM (uploaded once per scene, read-only afterwards) and the kernel parameter blocks.
+// See DESIGN.md "Data layout".  All f32 arrays are float4-granular so every fetch is one dwordx4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// prim meta word (prims[3*slot].w bits): type in bits 0-1, last-in-leaf in bit 2, type-local index above.
+constexpr uint32_t kMetaTypeMask = 3u;
+constexpr uint32_t kMetaLast = 4u;
+constexpr int kMetaIndexShift = 3;
+constexpr int kNoChild = 0x7fffffff;  // "empty" child of the synthetic root when the tree is one leaf
+
+// f64 records for the exact-parity kernel (array of structs; speed is irrelevant there).
+struct Node64 {
+    double lo[2][3], hi[2][3];  // child boxes, un-rounded
+    int32_t child[2];           // >= 0 inner node, < 0 leaf: ~first_slot, kNoChild: none
+    int32_t pad[2];
+};
+struct Prim64 {
+    int32_t type, last, surface, pad;
+    // tri: v0 v1 v2 (9)          sphere: c (3), r          quad: normal(3) d q(3) u(3) v(3) w(3)
+    double a[16];
+};
+
+struct DevCamera {
+    double origin[3];  // ray origins are carried in f64 (spheres/quads are intersected in f64)
+    float ll_rel[3];   // lower_left - origin            (f64 on host, then rounded)
+    float hor_px[3];   // horizontal / width
+    float ver_px[3];   // vertical / height
+    float u[3], v[3];  // lens basis
+    float lens_radius;
+};
+
+struct DevScene {
+    const float4* nodes;        // 4 per inner node: child-pair boxes (inflated, rounded outward) + child ids
+    const float4* prims;        // 3 per leaf slot, in-order leaf sequence: tri {v0|meta, e1, e2}
+    const float4* tri_shade;    // 3 per leaf slot: vertex normals n0 n1 n2; [0].w = material id bits
+    const double* spheres;      // 4 per sphere: c.xyz r
+    const double* quads;        // 16 per quad: normal(3) d q(3) A=v×w (3) B=w×u (3) pad(3)
+    const int32_t* sphere_mat;  // material id per sphere
+    const int32_t* quad_mat;    // material id per quad
+    const float4* materials;    // 1 per material: albedo.xyz, w = fuzz | refractive index
+    const int32_t* mat_kind;    // RT_MAT_* per material
+    const int32_t* slot_surface;  // surface id per leaf slot
+    const Node64* nodes64;
+    const Prim64* prims64;
+    float background[3];
+    DevCamera cam;
+    double cam64[4][3];  // origin, lower_left, horizontal, vertical (parity kernel)
+    uint32_t n_slots;
+};
+
+struct DevRenderParams {
+    uint32_t width, height, sn, max_depth;
+    uint32_t stratum_begin, stratum_step, n_strata;  // n_strata = sn*sn
+    uint32_t seed_lo, seed_hi;
+    float recip_sn;
+};
+
+struct DevCounters {  // one instance in HBM, bumped with one atomic per wave at kernel end
+    unsigned long long samples, segments, node_visits, tri_tests, sphere_tests, quad_tests;
+};
+
+}  // namespace rt

@@ -1,0 +1,135 @@
+#include "bvh_build.h"
+
+#include <algorithm>
+
+namespace rt {
+
+namespace {
+
+V3 v3(const double* p) { return {p[0], p[1], p[2]}; }
+
+struct Item {
+    Aabb box;
+    int32_t id;
+};
+
+const double kIntersectCost = 1.0;  // bvh.rs:15
+const double kTraversalCost = 2.0;  // bvh.rs:18
+const size_t kMaxLeafSize = 8;      // bvh.rs:23
+
+struct Builder {
+    std::vector<Item> items;
+    std::vector<Aabb> merge_left, merge_right;  // scratch for the sweep
+    Bvh* out = nullptr;
+
+    int32_t make_leaf(size_t first, size_t count, uint32_t depth) {
+        BvhNode n;
+        n.box = Aabb::empty();  // bvh.rs:290-293
+        for (size_t i = 0; i < count; ++i) n.box = n.box.merge(items[first + i].box);
+        n.first = (int32_t)first;
+        n.count = (int32_t)count;
+        out->nodes.push_back(n);
+        out->max_depth = std::max(out->max_depth, depth);
+        out->max_leaf_size = std::max(out->max_leaf_size, (uint32_t)count);
+        out->n_leaves++;
+        return (int32_t)out->nodes.size() - 1;
+    }
+
+    // SAHSplitStrategy::split_at, bvh.rs:131-174.  Returns 0 for "do not split".
+    size_t sah_split(size_t first, size_t n) {
+        if (n <= 1) return 0;
+        merge_left.resize(n);
+        merge_right.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            merge_left[i] = items[first + i].box;
+            merge_right[i] = items[first + n - 1 - i].box;
+        }
+        for (size_t i = 1; i < n; ++i) {
+            merge_left[i] = merge_left[i].merge(merge_left[i - 1]);
+            merge_right[i] = merge_right[i].merge(merge_right[i - 1]);
+        }
+        double no_split_cost = merge_left[n - 1].surface_area() * (double)n * kIntersectCost;
+        size_t best = 0;
+        double best_cost = 0.0;
+        for (size_t s = 1; s + 1 < n; ++s) {  // (1..len-1): the last candidate is len-2
+            const Aabb& l = merge_left[s - 1];
+            const Aabb& r = merge_right[n - s - 1];
+            double cost = kTraversalCost + l.surface_area() * (double)s * kIntersectCost +
+                          r.surface_area() * (double)(n - s) * kIntersectCost;
+            if (best == 0 || cost < best_cost) {  // min_by keeps the FIRST minimum
+                best = s;
+                best_cost = cost;
+            }
+        }
+        if (best == 0 || !(best_cost < no_split_cost)) return 0;
+        return best;
+    }
+
+    // BVHNode::new_with_strategy, bvh.rs:183-234
+    int32_t build(size_t first, size_t n, uint32_t depth) {
+        if (n <= kMaxLeafSize) return make_leaf(first, n, depth);
+        V3 mins{INFINITY, INFINITY, INFINITY}, maxs{-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = 0; i < n; ++i) {
+            V3 c = items[first + i].box.centroid();
+            mins = vmin(mins, c);
+            maxs = vmax(maxs, c);
+        }
+        V3 span = maxs - mins;
+        int axis = 0;
+        if (span.get(axis) < span.get(1)) axis = 1;
+        if (span.get(axis) < span.get(2)) axis = 2;
+        std::stable_sort(items.begin() + first, items.begin() + first + n,
+                         [axis](const Item& a, const Item& b) { return a.box.lo.get(axis) < b.box.lo.get(axis); });
+        size_t split = sah_split(first, n);
+        if (split == 0) return make_leaf(first, n, depth);
+        int32_t self = (int32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        int32_t l = build(first, split, depth + 1);
+        int32_t r = build(first + split, n - split, depth + 1);
+        BvhNode& node = out->nodes[self];
+        node.left = l;
+        node.right = r;
+        node.box = out->nodes[l].box.merge(out->nodes[r].box);
+        return self;
+    }
+};
+
+}  // namespace
+
+Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
+    switch (s.type) {
+        case RT_SURF_SPHERE: {
+            const rt_sphere& sp = d.spheres[s.index];
+            V3 c = v3(sp.center), r{sp.radius, sp.radius, sp.radius};
+            Aabb b{c - r, c + r};  // a negative radius yields an inverted box, as in the reference
+            return b.merge(b);
+        }
+        case RT_SURF_TRIANGLE: {
+            const rt_triangle& t = d.triangles[s.index];
+            V3 a = v3(t.v[0]), b = v3(t.v[1]), c = v3(t.v[2]);
+            return {vmin(vmin(a, b), c), vmax(vmax(a, b), c)};
+        }
+        default: {
+            const rt_quad& q = d.quads[s.index];
+            V3 a = v3(q.q), b = a + v3(q.u) + v3(q.v);
+            return Aabb{vmin(a, b), vmax(a, b)}.pad(0.0001);
+        }
+    }
+}
+
+void build_bvh(const rt_scene_desc& d, Bvh& out) {
+    out = Bvh{};
+    Builder b;
+    b.out = &out;
+    b.items.resize(d.n_surfaces);
+    for (size_t i = 0; i < d.n_surfaces; ++i) b.items[i] = {surface_bounds(d, d.surfaces[i]), (int32_t)i};
+    out.nodes.reserve(d.n_surfaces / 2 + 16);
+    if (d.use_bvh)
+        b.build(0, d.n_surfaces, 1);
+    else
+        b.make_leaf(0, d.n_surfaces, 1);
+    out.order.resize(d.n_surfaces);
+    for (size_t i = 0; i < d.n_surfaces; ++i) out.order[i] = b.items[i].id;
+}
+
+}  // namespace rt

@@ -1,0 +1,35 @@
+// Host BVH build with the reference's topology (bvh.rs:131-234): widest-centroid axis, STABLE sort by
+// bbox.min[axis], full SAH sweep, leaf <= 8 unless SAH declines to split.  Produces an index-based tree
+// (no pointer chasing) whose leaves are contiguous ranges of `order`, so `order` IS the in-order leaf
+// sequence that decides equal-t ties in the reference traversal (bvh.rs:272-273, 308).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../../include/rt.h"
+#include "vec3.h"
+
+namespace rt {
+
+struct BvhNode {
+    Aabb box;
+    int32_t left = -1, right = -1;  // inner: node indices; leaf: -1
+    int32_t first = 0, count = 0;   // leaf: range in Bvh::order
+    bool is_leaf() const { return left < 0; }
+};
+
+struct Bvh {
+    std::vector<BvhNode> nodes;   // nodes[0] is the root
+    std::vector<int32_t> order;   // surface ids, in-order over the leaves
+    uint32_t max_depth = 0;       // root = 1
+    uint32_t max_leaf_size = 0;
+    uint32_t n_leaves = 0;
+};
+
+// Bounding box of one surface: surfaces.rs:57-69 (sphere), 281-291 (triangle), 356-359 (quad).
+Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s);
+
+// use_bvh == false gives the single-leaf tree of Bvh::new_leaf (bvh.rs:63-68).
+void build_bvh(const rt_scene_desc& d, Bvh& out);
+
+}  // namespace rt

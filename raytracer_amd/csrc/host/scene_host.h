@@ -1,0 +1,42 @@
+// Host-side scene ownership: the vectors behind an rt_scene_desc, plus the loader entry point.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/rt.h"
+#include "vec3.h"
+
+namespace rt {
+
+// Owns the arrays an rt_scene_desc points at.  `desc` must stay the first member: rt_load_scene hands
+// out &desc and rt_scene_desc_free casts it back.
+struct HostScene {
+    rt_scene_desc desc{};
+    std::vector<rt_material> materials;
+    std::vector<rt_sphere> spheres;
+    std::vector<rt_triangle> triangles;
+    std::vector<rt_quad> quads;
+    std::vector<rt_surface_ref> surfaces;
+    void sync_desc();  // refresh desc pointers/counts after the vectors changed
+};
+
+// load.rs:39-160.  Throws std::runtime_error with an anyhow-like "context: cause" message.
+void load_scene_file(const std::string& yaml_path, double aspect_ratio, bool use_bvh, HostScene& out);
+
+// camera.rs:43-74
+rt_camera build_camera(double vfov_degrees, double aspect_ratio, V3 from, V3 towards, V3 vup, double aperture,
+                       bool has_focus, double focus_dist);
+
+// surfaces.rs:313-327
+rt_quad make_quad(V3 q, V3 u, V3 v, int material);
+
+struct ObjMesh {
+    std::string name;
+    std::vector<float> positions;  // xyz per vertex, f32 as tobj yields them (load.rs:258-261)
+    std::vector<float> normals;    // xyz per normal, may be empty
+    std::vector<uint32_t> indices; // 3 per triangle
+};
+// First model of an OBJ file, gunzipped iff the extension is "gz" (load.rs:202-229, 315-325).
+void load_obj_first_model(const std::string& path, ObjMesh& out);
+
+}  // namespace rt
