@@ -83,7 +83,7 @@ class RtStats(C.Structure):
                 ("kernel_ms", C.c_double), ("n_launches", C.c_uint32), ("_pad", C.c_uint32)]
 
 
-# numpy views of the flat scene arrays (zero-copy over the library-owned memory)
+# numpy record layouts of the flat scene arrays
 MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("_pad", "<i4"), ("albedo", "<f8", 3), ("param", "<f8")])
 SPHERE_DTYPE = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("material", "<i4"), ("_pad", "<i4")])
 TRIANGLE_DTYPE = np.dtype([("v", "<f8", (3, 3)), ("n", "<f8", (3, 3)), ("material", "<i4"), ("_pad", "<i4")])
@@ -150,7 +150,7 @@ def _view(ptr, n, dtype):
     if n == 0:
         return np.zeros(0, dtype=dtype)
     buf = (C.c_char * (n * dtype.itemsize)).from_address(C.addressof(ptr.contents))
-    return np.frombuffer(buf, dtype=dtype, count=n)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()  # a copy: the library frees the source with the desc
 
 
 class SceneDesc:
