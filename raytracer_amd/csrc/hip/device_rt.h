@@ -158,7 +158,12 @@ __device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& r
                                                 int stack_stride, TraceStats& st) {
     const F3 o = tof(ray.o);
     const F3 d = ray.d;
-    const float idx = __builtin_amdgcn_rcpf(d.x), idy = __builtin_amdgcn_rcpf(d.y), idz = __builtin_amdgcn_rcpf(d.z);
+    // A zero direction component would make lo*inf - o*inf a NaN or a wrongly signed infinity in the fma slab
+    // form below; clamp |d| away from zero (2^-80) so every slab bound stays finite and correctly ordered.
+    const float ooeps = 0x1p-80f;
+    const float idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+    const float idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+    const float idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
     const float oodx = o.x * idx, oody = o.y * idy, oodz = o.z * idz;
 
     HitRec best;
