@@ -115,11 +115,17 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
 typedef struct rt_scene_info {
+    /* the reference-topology tree (bvh.rs:131-234): parity kernel and equal-t tie ranks */
     uint64_t n_surfaces, n_nodes, n_leaves;
     uint32_t max_depth;     /* depth of the binary tree (root = 1) */
     uint32_t max_leaf_size; /* largest leaf (can exceed 8: bvh.rs:219,233) */
     uint64_t device_bytes;  /* bytes resident in HBM for this scene */
-    double build_ms;        /* host BVH build + flatten */
+    double build_ms;        /* host BVH builds + flatten */
+    /* the tree the f32 render kernels traverse (binned SAH; spheres/quads kept out of it when few) */
+    uint64_t render_nodes;
+    uint32_t render_depth, render_max_leaf;
+    uint32_t n_loose;       /* spheres + quads tested by every ray before traversal */
+    uint32_t _pad;
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* info);
 

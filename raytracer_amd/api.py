@@ -68,7 +68,8 @@ class RtSceneDesc(C.Structure):
 class RtSceneInfo(C.Structure):
     _fields_ = [("n_surfaces", C.c_uint64), ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64),
                 ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("build_ms", C.c_double)]
+                ("build_ms", C.c_double), ("render_nodes", C.c_uint64), ("render_depth", C.c_uint32),
+                ("render_max_leaf", C.c_uint32), ("n_loose", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class RtRenderParams(C.Structure):

@@ -69,9 +69,12 @@ float uint_bits(uint32_t v) {
 
 struct rt_scene {
     int device = -1;  // RT_DEVICE_NONE: host-only
-    Bvh bvh;
+    Bvh bvh;         // reference topology (bvh.rs:131-234): parity kernel + tie ranks
+    Bvh render_bvh;  // binned-SAH tree the f32 render kernels traverse
+    bool has_tree = false;
     rt_scene_info info{};
-    uint32_t stack_depth = 0;  // depth of the flattened tree incl. a synthetic root
+    uint32_t stack_depth = 0;  // depth of the flattened render tree incl. a synthetic root
+    uint32_t n_cus = 256;
     DevScene dev{};
     std::vector<void*> allocations;
     DevCounters* d_counters = nullptr;
@@ -80,6 +83,7 @@ struct rt_scene {
 
     // flattened host copies (kept for host-only inspection and tests)
     std::vector<float4> nodes, prims, tri_shade, materials;
+    std::vector<int4> loose;
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
     std::vector<Node64> nodes64;
@@ -133,45 +137,139 @@ void validate(const rt_scene_desc& d) {
     }
 }
 
-// Tree -> linear arrays.  Inner nodes keep their children's boxes (one fetch decides both children);
+struct FlatTree {
+    std::vector<int32_t> inner_id;  // tree node -> device node index (inner nodes only)
+    bool root_is_leaf = false;
+    size_t n_dev_nodes = 0;
+    explicit FlatTree(const Bvh& bvh) : inner_id(bvh.nodes.size(), -1) {
+        root_is_leaf = bvh.nodes.empty() || bvh.nodes[0].is_leaf();
+        int32_t n = 0;
+        for (size_t i = 0; i < bvh.nodes.size(); ++i)
+            if (!bvh.nodes[i].is_leaf()) inner_id[i] = n++;
+        n_dev_nodes = root_is_leaf ? 1 : (size_t)n;
+    }
+    int32_t child_ref(const Bvh& bvh, int32_t node) const {
+        const BvhNode& n = bvh.nodes[node];
+        return n.is_leaf() ? ~n.first : inner_id[node];
+    }
+};
+
+// Reference-topology tree -> f64 arrays of the exact-parity kernel.  Inner nodes keep their children's boxes;
 // leaves become runs of slots in the in-order sequence, closed by a last-in-leaf flag.
-void flatten(const rt_scene_desc& d, rt_scene& s) {
+void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
     const Bvh& bvh = s.bvh;
     const size_t n_surf = d.n_surfaces;
-    const bool root_is_leaf = bvh.nodes[0].is_leaf();
-    const size_t n_slots = n_surf + (root_is_leaf ? 1 : 0);
+    const FlatTree ft(bvh);
+    s.nodes64.assign(ft.n_dev_nodes, Node64{});
+    auto put = [&](size_t node, int c, const Aabb& b, int32_t ref) {
+        for (int a = 0; a < 3; ++a) s.nodes64[node].lo[c][a] = b.lo.get(a), s.nodes64[node].hi[c][a] = b.hi.get(a);
+        s.nodes64[node].child[c] = ref;
+    };
+    if (ft.root_is_leaf) {
+        put(0, 0, bvh.nodes[0].box, ~0);
+        put(0, 1, bvh.nodes[0].box, kNoChild);
+    } else {
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+            const BvhNode& n = bvh.nodes[i];
+            if (n.is_leaf()) continue;
+            put(ft.inner_id[i], 0, bvh.nodes[n.left].box, ft.child_ref(bvh, n.left));
+            put(ft.inner_id[i], 1, bvh.nodes[n.right].box, ft.child_ref(bvh, n.right));
+        }
+    }
+    std::vector<uint8_t> last(n_surf, 0);
+    for (const BvhNode& n : bvh.nodes)
+        if (n.is_leaf() && n.count > 0) last[n.first + n.count - 1] = 1;
+    s.prims64.assign(n_surf, Prim64{});
+    for (size_t slot = 0; slot < n_surf; ++slot) {
+        const int32_t sid = bvh.order[slot];
+        const rt_surface_ref& ref = d.surfaces[sid];
+        Prim64& p64 = s.prims64[slot];
+        p64.type = ref.type, p64.last = last[slot], p64.surface = sid;
+        if (ref.type == RT_SURF_TRIANGLE) {
+            const rt_triangle& t = d.triangles[ref.index];
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) p64.a[3 * k + a] = t.v[k][a];
+        } else if (ref.type == RT_SURF_SPHERE) {
+            const rt_sphere& sp = d.spheres[ref.index];
+            for (int a = 0; a < 3; ++a) p64.a[a] = sp.center[a];
+            p64.a[3] = sp.radius;
+        } else {
+            const rt_quad& q = d.quads[ref.index];
+            for (int a = 0; a < 3; ++a) {
+                p64.a[a] = q.normal[a], p64.a[4 + a] = q.q[a], p64.a[7 + a] = q.u[a];
+                p64.a[10 + a] = q.v[a], p64.a[13 + a] = q.w[a];
+            }
+            p64.a[3] = q.d;
+        }
+    }
+    s.info.n_surfaces = n_surf;
+    s.info.n_nodes = bvh.nodes.size();
+    s.info.n_leaves = bvh.n_leaves;
+    s.info.max_depth = bvh.max_depth;
+    s.info.max_leaf_size = bvh.max_leaf_size;
+}
+
+constexpr size_t kMaxLoose = 16;      // at most this many spheres+quads are tested by every ray ("loose")
+constexpr uint32_t kRenderLeaf = 4;   // leaf size of the render tree
+
+// Render tree + loose list -> f32 arrays of the render kernels.
+void flatten_render(const rt_scene_desc& d, rt_scene& s) {
+    const size_t n_surf = d.n_surfaces;
+    // rank = position in the reference tree's in-order leaf sequence: decides equal-t ties (bvh.rs:272-273,308)
+    std::vector<int32_t> rank(n_surf);
+    for (size_t i = 0; i < n_surf; ++i) rank[s.bvh.order[i]] = (int32_t)i;
+
+    const bool loose_ok = d.n_spheres + d.n_quads <= kMaxLoose;
+    std::vector<int32_t> tree_ids;
+    s.loose.clear();
+    for (size_t i = 0; i < n_surf; ++i) {
+        const rt_surface_ref& ref = d.surfaces[i];
+        if (ref.type != RT_SURF_TRIANGLE && loose_ok)
+            s.loose.push_back(int4{ref.type, ref.index, rank[i], (int32_t)i});
+        else
+            tree_ids.push_back((int32_t)i);
+    }
+    Bvh& rb = s.render_bvh;
+    if (d.use_bvh) {
+        build_render_bvh(d, tree_ids, kRenderLeaf, rb);
+    } else {  // --no-bvh: one leaf, every surface tested by every ray (main.rs:60-65)
+        rb = Bvh{};
+        rb.order = tree_ids;
+        if (!tree_ids.empty()) {
+            BvhNode leaf;
+            leaf.box = Aabb::empty();
+            for (int32_t id : tree_ids) {
+                Aabb b = surface_bounds(d, d.surfaces[id]);
+                leaf.box = leaf.box.merge(Aabb{vmin(b.lo, b.hi), vmax(b.lo, b.hi)});
+            }
+            leaf.first = 0, leaf.count = (int32_t)tree_ids.size();
+            rb.nodes.push_back(leaf);
+            rb.max_depth = 1, rb.n_leaves = 1, rb.max_leaf_size = (uint32_t)tree_ids.size();
+        }
+    }
+    const size_t n_tree = tree_ids.size();
+    s.has_tree = n_tree > 0;
+    const FlatTree ft(rb);
+    const size_t n_slots = n_tree + ((s.has_tree && ft.root_is_leaf) ? 1 : 0);
 
     // f32 boxes must stay conservative under the fma slab form lo*inv_d - o*inv_d, whose rounding error in
     // position space is about |o| * 2^-24: inflate every box by the scene's largest coordinate * 2^-22.
     double maxabs = 0.0;
+    const Aabb& all = s.bvh.nodes[0].box;
     for (int a = 0; a < 3; ++a) {
-        maxabs = std::fmax(maxabs, std::fabs(bvh.nodes[0].box.lo.get(a)));
-        maxabs = std::fmax(maxabs, std::fabs(bvh.nodes[0].box.hi.get(a)));
+        maxabs = std::fmax(maxabs, std::fabs(all.lo.get(a)));
+        maxabs = std::fmax(maxabs, std::fabs(all.hi.get(a)));
         maxabs = std::fmax(maxabs, std::fabs(d.camera.origin[a]));
     }
     const double inflate = maxabs * 0x1p-22;
 
-    std::vector<int32_t> inner_id(bvh.nodes.size(), -1);
-    int32_t n_inner = 0;
-    for (size_t i = 0; i < bvh.nodes.size(); ++i)
-        if (!bvh.nodes[i].is_leaf()) inner_id[i] = n_inner++;
-    auto child_ref = [&](int32_t node) -> int32_t {
-        const BvhNode& n = bvh.nodes[node];
-        return n.is_leaf() ? ~n.first : inner_id[node];
-    };
-
-    const size_t n_dev_nodes = root_is_leaf ? 1 : (size_t)n_inner;
-    s.nodes.assign(4 * n_dev_nodes, float4{0, 0, 0, 0});
-    s.nodes64.assign(n_dev_nodes, Node64{});
+    s.nodes.assign(4 * std::max<size_t>(ft.n_dev_nodes, 1), float4{0, 0, 0, 0});
     auto put_child = [&](size_t node, int c, const Aabb& b, int32_t ref) {
         float lo[3], hi[3];
         for (int a = 0; a < 3; ++a) {
             lo[a] = round_down(b.lo.get(a) - inflate);
             hi[a] = round_up(b.hi.get(a) + inflate);
-            s.nodes64[node].lo[c][a] = b.lo.get(a);
-            s.nodes64[node].hi[c][a] = b.hi.get(a);
         }
-        s.nodes64[node].child[c] = ref;
         float4* n = &s.nodes[4 * node];
         if (c == 0) {
             n[0] = {lo[0], lo[1], lo[2], hi[0]};
@@ -183,71 +281,50 @@ void flatten(const rt_scene_desc& d, rt_scene& s) {
             n[3].y = int_bits(ref);
         }
     };
-    if (root_is_leaf) {
-        // synthetic root: child 0 = the leaf; child 1 = a far-away point box over one dummy slot that
-        // can never be hit (the f64 kernel skips it via kNoChild)
-        put_child(0, 0, bvh.nodes[0].box, ~0);
+    s.stack_depth = 2;
+    if (s.has_tree && ft.root_is_leaf) {
+        // synthetic root: child 0 = the leaf; child 1 = a far-away point box over one dummy slot (a
+        // degenerate triangle) that can never be hit
+        put_child(0, 0, rb.nodes[0].box, ~0);
         Aabb far{{1e30, 1e30, 1e30}, {1e30, 1e30, 1e30}};
-        put_child(0, 1, far, ~(int32_t)n_surf);
-        s.nodes64[0].child[1] = kNoChild;
-        s.stack_depth = 2;
-    } else {
-        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
-            const BvhNode& n = bvh.nodes[i];
+        put_child(0, 1, far, ~(int32_t)n_tree);
+    } else if (s.has_tree) {
+        for (size_t i = 0; i < rb.nodes.size(); ++i) {
+            const BvhNode& n = rb.nodes[i];
             if (n.is_leaf()) continue;
-            put_child(inner_id[i], 0, bvh.nodes[n.left].box, child_ref(n.left));
-            put_child(inner_id[i], 1, bvh.nodes[n.right].box, child_ref(n.right));
+            put_child(ft.inner_id[i], 0, rb.nodes[n.left].box, ft.child_ref(rb, n.left));
+            put_child(ft.inner_id[i], 1, rb.nodes[n.right].box, ft.child_ref(rb, n.right));
         }
-        s.stack_depth = bvh.max_depth;
+        s.stack_depth = rb.max_depth;
     }
 
-    // leaf slots
-    std::vector<uint8_t> last(n_slots, 0);
-    for (const BvhNode& n : bvh.nodes)
+    std::vector<uint8_t> last(std::max<size_t>(n_slots, 1), 0);
+    for (const BvhNode& n : rb.nodes)
         if (n.is_leaf() && n.count > 0) last[n.first + n.count - 1] = 1;
-    s.prims.assign(3 * n_slots, float4{0, 0, 0, 0});
-    s.tri_shade.assign(3 * n_slots, float4{0, 0, 0, 0});
-    s.prims64.assign(n_slots, Prim64{});
-    s.slot_surface.assign(n_slots, -1);
-    for (size_t slot = 0; slot < n_surf; ++slot) {
-        const int32_t sid = bvh.order[slot];
+    s.prims.assign(3 * std::max<size_t>(n_slots, 1), float4{0, 0, 0, 0});
+    s.tri_shade.assign(3 * std::max<size_t>(n_slots, 1), float4{0, 0, 0, 0});
+    s.slot_surface.assign(std::max<size_t>(n_slots, 1), -1);
+    for (size_t slot = 0; slot < n_tree; ++slot) {
+        const int32_t sid = rb.order[slot];
         const rt_surface_ref& ref = d.surfaces[sid];
         s.slot_surface[slot] = sid;
-        Prim64& p64 = s.prims64[slot];
-        p64.type = ref.type, p64.last = last[slot], p64.surface = sid;
         uint32_t meta = (uint32_t)ref.type | (last[slot] ? kMetaLast : 0u);
         float4* p = &s.prims[3 * slot];
         if (ref.type == RT_SURF_TRIANGLE) {
             const rt_triangle& t = d.triangles[ref.index];
-            for (int k = 0; k < 3; ++k)
-                for (int a = 0; a < 3; ++a) p64.a[3 * k + a] = t.v[k][a];
             p[0] = {(float)t.v[0][0], (float)t.v[0][1], (float)t.v[0][2], uint_bits(meta)};
             p[1] = {(float)(t.v[1][0] - t.v[0][0]), (float)(t.v[1][1] - t.v[0][1]), (float)(t.v[1][2] - t.v[0][2]), 0};
             p[2] = {(float)(t.v[2][0] - t.v[0][0]), (float)(t.v[2][1] - t.v[0][1]), (float)(t.v[2][2] - t.v[0][2]), 0};
             float4* sh = &s.tri_shade[3 * slot];
             for (int k = 0; k < 3; ++k) sh[k] = {(float)t.n[k][0], (float)t.n[k][1], (float)t.n[k][2], 0};
             sh[0].w = int_bits(t.material);
-        } else if (ref.type == RT_SURF_SPHERE) {
-            const rt_sphere& sp = d.spheres[ref.index];
-            for (int a = 0; a < 3; ++a) p64.a[a] = sp.center[a];
-            p64.a[3] = sp.radius;
-            meta |= (uint32_t)ref.index << kMetaIndexShift;
-            p[0].w = uint_bits(meta);
         } else {
-            const rt_quad& q = d.quads[ref.index];
-            for (int a = 0; a < 3; ++a) {
-                p64.a[a] = q.normal[a], p64.a[4 + a] = q.q[a], p64.a[7 + a] = q.u[a];
-                p64.a[10 + a] = q.v[a], p64.a[13 + a] = q.w[a];
-            }
-            p64.a[3] = q.d;
             meta |= (uint32_t)ref.index << kMetaIndexShift;
             p[0].w = uint_bits(meta);
         }
+        p[1].w = int_bits(rank[sid]);
     }
-    if (root_is_leaf) {  // the dummy slot: a degenerate triangle (det == 0 -> never hit)
-        s.prims[3 * n_surf].w = uint_bits(1u | kMetaLast);
-        s.prims64[n_surf].type = 1, s.prims64[n_surf].last = 1, s.prims64[n_surf].surface = -1;
-    }
+    if (s.has_tree && ft.root_is_leaf) s.prims[3 * n_tree].w = uint_bits(1u | kMetaLast);
 
     s.spheres.resize(4 * d.n_spheres);
     s.sphere_mat.resize(d.n_spheres);
@@ -275,12 +352,10 @@ void flatten(const rt_scene_desc& d, rt_scene& s) {
         s.materials[i] = {(float)m.albedo[0], (float)m.albedo[1], (float)m.albedo[2], (float)m.param};
         s.mat_kind[i] = m.kind;
     }
-
-    s.info.n_surfaces = n_surf;
-    s.info.n_nodes = bvh.nodes.size();
-    s.info.n_leaves = bvh.n_leaves;
-    s.info.max_depth = bvh.max_depth;
-    s.info.max_leaf_size = bvh.max_leaf_size;
+    s.info.render_nodes = rb.nodes.size();
+    s.info.render_depth = s.stack_depth;
+    s.info.render_max_leaf = rb.max_leaf_size;
+    s.info.n_loose = (uint32_t)s.loose.size();
 }
 
 void fill_camera(const rt_scene_desc& d, DevScene& dev) {
@@ -369,13 +444,16 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         auto s = std::make_unique<rt_scene>();
         auto t0 = std::chrono::steady_clock::now();
         build_bvh(*desc, s->bvh);
-        flatten(*desc, *s);
+        flatten_reference64(*desc, *s);
+        flatten_render(*desc, *s);
         s->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (s->stack_depth > 64)
             throw std::runtime_error("BVH depth " + std::to_string(s->stack_depth) +
                                      " exceeds the traversal stack (64 levels)");
         fill_camera(*desc, s->dev);
         s->dev.n_slots = (uint32_t)s->slot_surface.size();
+        s->dev.n_loose = (uint32_t)s->loose.size();
+        s->dev.has_tree = s->has_tree ? 1u : 0u;
         if (device == RT_DEVICE_NONE) {
             s->device = -1;
             *out = s.release();
@@ -387,6 +465,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.nodes = upload(*s, s->nodes);
         s->dev.prims = upload(*s, s->prims);
         s->dev.tri_shade = upload(*s, s->tri_shade);
+        s->dev.loose = upload(*s, s->loose);
         s->dev.spheres = upload(*s, s->spheres);
         s->dev.quads = upload(*s, s->quads);
         s->dev.sphere_mat = upload(*s, s->sphere_mat);
@@ -398,6 +477,9 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.prims64 = upload(*s, s->prims64);
         std::vector<DevCounters> zero(1);
         s->d_counters = const_cast<DevCounters*>(upload(*s, zero));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        s->n_cus = (uint32_t)prop.multiProcessorCount;
         HIP_CHECK(hipEventCreate(&s->ev0));
         HIP_CHECK(hipEventCreate(&s->ev1));
         *out = s.release();
@@ -435,7 +517,8 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
         if (stats) HIP_CHECK(hipEventRecord(scene->ev0, stream));
         uint32_t n_launches = 1;
         if (params->kernel == RT_KERNEL_PERSISTENT) {
-            HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, d_rgb_sum, scene->d_counters, count, stream));
+            HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, d_rgb_sum, scene->d_counters,
+                                               &scene->d_counters->work, count, stream));
         } else if (params->kernel == RT_KERNEL_WAVEFRONT) {
             if (!scene->wf) scene->wf = std::make_unique<WavefrontState>();
             HIP_CHECK(render_wavefront(*scene->wf, dev, rp, scene->stack_depth, d_rgb_sum, scene->d_counters, count,

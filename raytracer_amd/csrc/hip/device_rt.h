@@ -151,11 +151,41 @@ __device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double 
 }
 
 // ---------------------------------------------------------------- traversal
+// Hit encoding: slot >= 0 is a leaf slot of the render tree, slot <= -2 is loose primitive (-2 - slot),
+// -1 is a miss.  Closest wins; an exact tie goes to the surface that comes later in the reference tree's
+// in-order leaf sequence (its "rank"), which is what the reference's recursion yields (bvh.rs:272-273, 308).
+//
 // `stack` points at this lane's column of an LDS array laid out [level][lane] (stride = block size), so
 // a push/pop is one conflict-free ds_write/ds_read.  The host checks tree depth <= stack levels.
 template <bool STATS>
 __device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& ray, float tmin, int* stack,
                                                 int stack_stride, TraceStats& st) {
+    HitRec best;
+    best.t = __builtin_inff();
+    best.slot = -1;
+    best.bu = best.bv = 0.f;
+    int best_rank = -1;
+    const D3 dd = d3(ray.d);
+
+    // ---- loose spheres/quads: every lane tests the same primitive at the same time (no divergence, the
+    // records come through the scalar cache); f64 because radius-1000 spheres and 555-unit walls need it
+    for (uint32_t i = 0; i < sc.n_loose; ++i) {
+        const int4 m = sc.loose[i];
+        double t;
+        if (m.x == 0) {
+            if (STATS) st.spheres++;
+            t = sphere_root(sc.spheres + 4 * m.y, ray.o, dd, (double)tmin, (double)best.t);
+        } else {
+            if (STATS) st.quads++;
+            t = quad_root(sc.quads + 16 * m.y, ray.o, dd, (double)tmin, (double)best.t);
+        }
+        const float tf = (float)t;
+        if (tf >= tmin && (tf < best.t || (tf == best.t && m.z > best_rank))) {
+            best.t = tf, best.slot = -2 - (int)i, best_rank = m.z;
+        }
+    }
+    if (!sc.has_tree) return best;
+
     const F3 o = tof(ray.o);
     const F3 d = ray.d;
     // A zero direction component would make lo*inf - o*inf a NaN or a wrongly signed infinity in the fma slab
@@ -165,11 +195,6 @@ __device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& r
     const float idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
     const float idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
     const float oodx = o.x * idx, oody = o.y * idy, oodz = o.z * idz;
-
-    HitRec best;
-    best.t = __builtin_inff();
-    best.slot = -1;
-    best.bu = best.bv = 0.f;
 
     int sp = 0;
     int node = 0;  // root is always an inner node (a single-leaf tree gets a synthetic root)
@@ -211,52 +236,50 @@ __device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& r
                 node = stack[sp * stack_stride];
             }
         }
-        // ---- leaf: scan slots until the last-in-leaf flag (bvh.rs:300-314)
-        if (node != kNoChild) {
-            int slot = ~node;
-            while (true) {
-                const float4 p0 = sc.prims[3 * slot + 0];
-                const uint32_t meta = __float_as_uint(p0.w);
-                const uint32_t type = meta & kMetaTypeMask;
-                float t = -1.f, bu = 0.f, bv = 0.f;
-                if (type == 1u) {  // triangle, Möller–Trumbore with host-precomputed edges
-                    if (STATS) st.tris++;
-                    const float4 p1 = sc.prims[3 * slot + 1];
-                    const float4 p2 = sc.prims[3 * slot + 2];
-                    const F3 e1 = f3(p1), e2 = f3(p2);
-                    const F3 pvec = cross(d, e2);
-                    const float det = dot(e1, pvec);
-                    if (!(-1e-8f < det && det < 1e-8f)) {
-                        const float inv_det = __builtin_amdgcn_rcpf(det);
-                        const F3 tvec = o - f3(p0);
-                        const float u = dot(tvec, pvec) * inv_det;
-                        if (u >= 0.f && u <= 1.f) {
-                            const F3 qvec = cross(tvec, e1);
-                            const float v = dot(d, qvec) * inv_det;
-                            if (!(v < 0.f || u + v > 1.f)) {
-                                const float tt = dot(e2, qvec) * inv_det;
-                                if (!(tt < 1e-4f) && tmin <= tt) {
-                                    t = tt, bu = u, bv = v;
-                                }
+        // ---- leaf: scan slots until the last-in-leaf flag
+        int slot = ~node;
+        while (true) {
+            const float4 p0 = sc.prims[3 * slot + 0];
+            const float4 p1 = sc.prims[3 * slot + 1];
+            const uint32_t meta = __float_as_uint(p0.w);
+            const uint32_t type = meta & kMetaTypeMask;
+            float t = -1.f, bu = 0.f, bv = 0.f;
+            if (type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
+                if (STATS) st.tris++;
+                const float4 p2 = sc.prims[3 * slot + 2];
+                const F3 e1 = f3(p1), e2 = f3(p2);
+                const F3 pvec = cross(d, e2);
+                const float det = dot(e1, pvec);
+                if (!(-1e-8f < det && det < 1e-8f)) {
+                    const float inv_det = __builtin_amdgcn_rcpf(det);
+                    const F3 tvec = o - f3(p0);
+                    const float u = dot(tvec, pvec) * inv_det;
+                    if (u >= 0.f && u <= 1.f) {
+                        const F3 qvec = cross(tvec, e1);
+                        const float v = dot(d, qvec) * inv_det;
+                        if (!(v < 0.f || u + v > 1.f)) {
+                            const float tt = dot(e2, qvec) * inv_det;
+                            if (!(tt < 1e-4f) && tmin <= tt) {
+                                t = tt, bu = u, bv = v;
                             }
                         }
                     }
-                } else if (type == 0u) {
-                    if (STATS) st.spheres++;
-                    const double* spd = sc.spheres + 4 * (meta >> kMetaIndexShift);
-                    t = (float)sphere_root(spd, ray.o, d3(d), (double)tmin, (double)best.t);
-                } else {
-                    if (STATS) st.quads++;
-                    const double* qd = sc.quads + 16 * (meta >> kMetaIndexShift);
-                    t = (float)quad_root(qd, ray.o, d3(d), (double)tmin, (double)best.t);
                 }
-                // closest wins; an exact tie goes to the later slot of the in-order leaf sequence
-                if (t >= tmin && (t < best.t || (t == best.t && slot > best.slot))) {
-                    best.t = t, best.slot = slot, best.bu = bu, best.bv = bv;
-                }
-                if (meta & kMetaLast) break;
-                ++slot;
+            } else if (type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
+                if (STATS) st.spheres++;
+                t = (float)sphere_root(sc.spheres + 4 * (meta >> kMetaIndexShift), ray.o, dd, (double)tmin, (double)best.t);
+            } else {
+                if (STATS) st.quads++;
+                t = (float)quad_root(sc.quads + 16 * (meta >> kMetaIndexShift), ray.o, dd, (double)tmin, (double)best.t);
             }
+            if (t >= tmin && t <= best.t) {
+                const int rank = __float_as_int(p1.w);
+                if (t < best.t || rank > best_rank) {
+                    best.t = t, best.slot = slot, best.bu = bu, best.bv = bv, best_rank = rank;
+                }
+            }
+            if (meta & kMetaLast) break;
+            ++slot;
         }
         if (sp == 0) return best;
         --sp;
@@ -272,13 +295,18 @@ __device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (2.0f * dot(v, n)
 // path continues; `depth` follows the reference's counter including the metal re-sampling quirk (Q1).
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const HitRec& hit, float tmin, Rng& rng,
                                              F3& thr, F3& lsum, uint32_t& depth, uint32_t max_depth) {
-    if (hit.slot < 0) {  // escaped: (0, background), scene/mod.rs:122
+    if (hit.slot == -1) {  // escaped: (0, background), scene/mod.rs:122
         lsum = lsum + thr * f3(sc.background);
         return false;
     }
-    const float4 p0 = sc.prims[3 * hit.slot];
-    const uint32_t meta = __float_as_uint(p0.w);
-    const uint32_t type = meta & kMetaTypeMask;
+    uint32_t type, index;
+    if (hit.slot >= 0) {
+        const uint32_t meta = __float_as_uint(sc.prims[3 * hit.slot].w);
+        type = meta & kMetaTypeMask, index = meta >> kMetaIndexShift;
+    } else {
+        const int4 m = sc.loose[-2 - hit.slot];
+        type = (uint32_t)m.x, index = (uint32_t)m.y;
+    }
     const D3 dd = d3(ray.d);
     F3 n;
     int mat;
@@ -292,22 +320,20 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
         mat = __float_as_int(s0.w);
         p = ray.o + (double)hit.t * dd;
     } else if (type == 0u) {
-        const uint32_t i = meta >> kMetaIndexShift;
-        const double* spd = sc.spheres + 4 * i;
-        double t = sphere_root(spd, ray.o, dd, (double)tmin, __builtin_inf());
+        const double* spd = sc.spheres + 4 * index;
+        double t = sphere_root(spd, ray.o, dd, (double)tmin, __builtin_inf());  // the f64 root (hit.t is rounded)
         if (t < 0.0) t = (double)hit.t;
         p = ray.o + t * dd;
         D3 nn = (1.0 / spd[3]) * (p - d3(spd));  // signed radius: a negative one flips the normal
         n = tof(nn);
-        mat = sc.sphere_mat[i];
+        mat = sc.sphere_mat[index];
     } else {
-        const uint32_t i = meta >> kMetaIndexShift;
-        const double* qd = sc.quads + 16 * i;
+        const double* qd = sc.quads + 16 * index;
         double t = quad_root(qd, ray.o, dd, (double)tmin, __builtin_inf());
         if (t < 0.0) t = (double)hit.t;
         p = ray.o + t * dd;
         n = tof(d3(qd));
-        mat = sc.quad_mat[i];
+        mat = sc.quad_mat[index];
     }
     // Hit::new, trace.rs:59-76: front face from the (shading) normal (Q4)
     const bool front = dot(ray.d, n) < 0.0f;

@@ -34,9 +34,15 @@ struct DevCamera {
 };
 
 struct DevScene {
+    // render tree (binned SAH, leaves <= 4): triangles, plus spheres/quads when a scene has too many of
+    // them to test "loose"
     const float4* nodes;        // 4 per inner node: child-pair boxes (inflated, rounded outward) + child ids
-    const float4* prims;        // 3 per leaf slot, in-order leaf sequence: tri {v0|meta, e1, e2}
+    const float4* prims;        // 3 per leaf slot: tri {v0|meta, e1|rank, e2}; rank = position in the
+                                //   reference tree's in-order leaf sequence (decides equal-t ties)
     const float4* tri_shade;    // 3 per leaf slot: vertex normals n0 n1 n2; [0].w = material id bits
+    const int4* loose;          // spheres/quads tested by every ray before traversal: type, index, rank, surface id
+    uint32_t n_loose;
+    uint32_t has_tree;          // 0: no surface lives in the render tree (all are loose)
     const double* spheres;      // 4 per sphere: c.xyz r
     const double* quads;        // 16 per quad: normal(3) d q(3) A=v×w (3) B=w×u (3) pad(3)
     const int32_t* sphere_mat;  // material id per sphere
@@ -61,6 +67,8 @@ struct DevRenderParams {
 
 struct DevCounters {  // one instance in HBM, bumped with one atomic per wave at kernel end
     unsigned long long samples, segments, node_visits, tri_tests, sphere_tests, quad_tests;
+    unsigned int work;  // chunk cursor of the persistent kernel
+    unsigned int pad;
 };
 
 }  // namespace rt

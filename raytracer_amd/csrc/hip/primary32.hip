@@ -22,8 +22,8 @@ __global__ __launch_bounds__(kPBlock) void primary32_kernel(DevScene sc, uint32_
     ray.d = f3(sc.cam.ll_rel) + (float)(pi + 1) * f3(sc.cam.hor_px) + (float)(pj + 1) * f3(sc.cam.ver_px);
     TraceStats st;
     const HitRec h = trace_closest<false>(sc, ray, 0.001f, lds_stack + threadIdx.x, kPBlock, st);
-    prim_id[idx] = h.slot >= 0 ? sc.slot_surface[h.slot] : -1;
-    t_out[idx] = h.slot >= 0 ? (double)h.t : -1.0;
+    prim_id[idx] = h.slot >= 0 ? sc.slot_surface[h.slot] : (h.slot == -1 ? -1 : sc.loose[-2 - h.slot].w);
+    t_out[idx] = h.slot != -1 ? (double)h.t : -1.0;
 }
 
 hipError_t launch_primary32(const DevScene& sc, uint32_t width, uint32_t height, uint32_t tree_depth,

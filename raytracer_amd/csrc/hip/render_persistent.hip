@@ -1,69 +1,112 @@
-// Persistent ("megakernel") form of the per-pixel render loop main.rs:150-185: one lane owns one pixel and
-// walks its strata; a lane whose path ended regenerates the next camera ray at once, so every lane of a
-// wave traces one ray segment per loop trip until its pixel is done (no per-sample re-convergence).
-// Radiance is summed in registers and written once: the only HBM traffic besides scene fetches is
-// 12 B per pixel.
+// Persistent form of the per-pixel render loop main.rs:150-185.
+//
+// Work is the stream of all (tile, strata-group, pixel, stratum) samples, cut into chunks of one 8x8 pixel
+// tile x up to 16 strata.  A fixed, CU-filling grid of waves pulls chunks from one global counter (one atomic
+// per ~1024 samples) and hands the samples of the current chunk to its lanes through a wave-uniform cursor:
+// a lane whose path ended takes the next sample at once (ballot + mbcnt, no LDS, no barrier), so every lane
+// traces one ray segment per loop trip whatever the mix of sky, ground and mesh pixels in the tile, and a
+// wave that drew cheap tiles simply pulls more chunks (no static pixel ownership, no tail of heavy waves).
+// A finished path adds its radiance to the f32 framebuffer with three float atomics — a path contributes
+// exactly once (at a light, at the sky, or nothing), so that is 12 B of atomic traffic per sample and the
+// only HBM traffic besides scene fetches.
+#include <algorithm>
+
 #include "device_rt.h"
 #include "kernels.h"
 
 namespace rt {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kChunkStrata = 16;  // strata per chunk (a chunk is 64 pixels x this many strata)
+
+struct PersistentPlan {
+    uint32_t tiles_x, n_tiles;
+    uint32_t my_strata;      // strata this call renders (begin, begin+step, ...)
+    uint32_t groups;         // ceil(my_strata / kChunkStrata)
+    uint32_t n_chunks;       // n_tiles * groups
+};
 
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, DevRenderParams rp,
+__global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ rgb_sum,
-                                                                   DevCounters* __restrict__ counters) {
+                                                                   DevCounters* __restrict__ counters,
+                                                                   uint32_t* __restrict__ work_counter) {
     __shared__ int lds_stack[STACK * kBlock];
     int* stack = lds_stack + threadIdx.x;
-
-    // A wave covers an 8x8 pixel tile (coherent primary rays); tiles in row-major order.
-    const uint32_t tiles_x = (rp.width + 7u) >> 3;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t px = (wave % tiles_x) * 8u + (lane & 7u);
-    const uint32_t py = (wave / tiles_x) * 8u + (lane >> 3);  // image row, 0 = top
-    const bool valid = px < rp.width && py < rp.height;
-    const uint32_t idx = py * rp.width + px;  // == reference's idx: pi = idx % W, pj = H - idx/W - 1
-    const uint32_t pj = rp.height - py - 1u;
     const uint64_t seed = ((uint64_t)rp.seed_hi << 32) | rp.seed_lo;
 
-    F3 lsum = {0.f, 0.f, 0.f};
-    F3 thr = {1.f, 1.f, 1.f};
+    // wave-uniform cursor over the current chunk
+    uint32_t chunk_tile = 0, chunk_group = 0, next_j = 0, chunk_total = 0;
+    bool exhausted = false;
+
+    // per-lane path state
+    F3 lsum = {0.f, 0.f, 0.f}, thr = {1.f, 1.f, 1.f};
     Ray ray;
     ray.o = {0., 0., 0.};
     ray.d = {0.f, 0.f, 1.f};
     Rng rng;
     rng.s = 0;
-    uint32_t depth = 0;
-    uint32_t next = valid ? rp.stratum_begin : rp.n_strata;
+    uint32_t depth = 0, pix = 0;
     bool alive = false;
     TraceStats st;
-    uint32_t n_segments = 0, n_samples = 0;
+    uint32_t n_segments = 0;
 
     while (true) {
-        if (!alive) {
-            if (next >= rp.n_strata) break;
-            rng_init(rng, seed, idx, next);
-            ray = camera_ray(sc, rp, px, pj, next, rng);
-            next += rp.stratum_step;
-            thr = {1.f, 1.f, 1.f};
-            depth = 0;
-            alive = true;
-            if (STATS) n_samples++;
+        // ---- refill: lanes without a path take the next samples of the chunk (uniform control flow)
+        unsigned long long need = __ballot(!alive);
+        while (need != 0ull && !exhausted) {
+            if (next_j >= chunk_total) {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(work_counter, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= plan.n_chunks) {
+                    exhausted = true;
+                    break;
+                }
+                // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
+                chunk_group = c / plan.n_tiles;
+                chunk_tile = c - chunk_group * plan.n_tiles;
+                const uint32_t strata_here = min(kChunkStrata, plan.my_strata - chunk_group * kChunkStrata);
+                chunk_total = 64u * strata_here;
+                next_j = 0;
+            }
+            const uint32_t avail = chunk_total - next_j;
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!alive && before < avail) {
+                const uint32_t j = next_j + before;
+                const uint32_t in_tile = j & 63u;
+                const uint32_t px = (chunk_tile % plan.tiles_x) * 8u + (in_tile & 7u);
+                const uint32_t py = (chunk_tile / plan.tiles_x) * 8u + (in_tile >> 3);  // image row, 0 = top
+                if (px < rp.width && py < rp.height) {
+                    const uint32_t stratum = rp.stratum_begin + (chunk_group * kChunkStrata + (j >> 6)) * rp.stratum_step;
+                    pix = py * rp.width + px;  // == the reference's idx: pi = idx % W, pj = H - idx/W - 1
+                    rng_init(rng, seed, pix, stratum);
+                    ray = camera_ray(sc, rp, px, rp.height - py - 1u, stratum, rng);
+                    thr = {1.f, 1.f, 1.f};
+                    lsum = {0.f, 0.f, 0.f};
+                    depth = 0;
+                    alive = true;
+                }
+            }
+            next_j += min((uint32_t)__popcll(need), avail);
+            need = __ballot(!alive);
         }
-        const HitRec hit = trace_closest<STATS>(sc, ray, 0.001f, stack, kBlock, st);  // scene/mod.rs:104
-        if (STATS) n_segments++;
-        alive = shade_bounce(sc, ray, hit, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+        if (__ballot(alive) == 0ull) break;  // nothing in flight and no work left
+
+        if (alive) {
+            const HitRec hit = trace_closest<STATS>(sc, ray, 0.001f, stack, kBlock, st);  // scene/mod.rs:104
+            if (STATS) n_segments++;
+            alive = shade_bounce(sc, ray, hit, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+            if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
+                atomicAdd(&rgb_sum[3 * pix + 0], lsum.x);
+                atomicAdd(&rgb_sum[3 * pix + 1], lsum.y);
+                atomicAdd(&rgb_sum[3 * pix + 2], lsum.z);
+            }
+        }
     }
 
-    if (valid) {
-        rgb_sum[3 * idx + 0] = lsum.x;
-        rgb_sum[3 * idx + 1] = lsum.y;
-        rgb_sum[3 * idx + 2] = lsum.z;
-    }
     if (STATS) {
-        atomicAdd(&counters->samples, (unsigned long long)n_samples);
         atomicAdd(&counters->segments, (unsigned long long)n_segments);
         atomicAdd(&counters->node_visits, (unsigned long long)st.nodes);
         atomicAdd(&counters->tri_tests, (unsigned long long)st.tris);
@@ -73,25 +116,41 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
 }
 
 template <int STACK>
-static hipError_t launch_stack(const DevScene& sc, const DevRenderParams& rp, float* d_rgb_sum, DevCounters* counters,
-                               bool stats, hipStream_t stream) {
-    const uint32_t tiles = ((rp.width + 7u) >> 3) * ((rp.height + 7u) >> 3);
-    const uint32_t blocks = (tiles * 64u + kBlock - 1) / kBlock;
+static hipError_t launch_stack(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
+                               float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter, bool stats,
+                               hipStream_t stream) {
     if (stats)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, true>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp,
-                           d_rgb_sum, counters);
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, true>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp, plan,
+                           d_rgb_sum, counters, work_counter);
     else
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, false>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp,
-                           d_rgb_sum, counters);
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, false>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp, plan,
+                           d_rgb_sum, counters, work_counter);
     return hipGetLastError();
 }
 
 hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& rp, uint32_t tree_depth,
-                                    float* d_rgb_sum, DevCounters* counters, bool stats, hipStream_t stream) {
+                                    uint32_t n_cus, float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter,
+                                    bool stats, hipStream_t stream) {
+    PersistentPlan plan;
+    plan.tiles_x = (rp.width + 7u) >> 3;
+    plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
+    plan.my_strata =
+        rp.stratum_begin >= rp.n_strata ? 0 : (rp.n_strata - rp.stratum_begin + rp.stratum_step - 1) / rp.stratum_step;
+    plan.groups = (plan.my_strata + kChunkStrata - 1) / kChunkStrata;
+    if ((uint64_t)plan.n_tiles * plan.groups >= (1ull << 32)) return hipErrorInvalidValue;
+    plan.n_chunks = plan.n_tiles * plan.groups;
+
+    hipError_t e = hipMemsetAsync(d_rgb_sum, 0, (size_t)3 * rp.width * rp.height * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+    if (plan.n_chunks == 0) return hipSuccess;
+    // Enough blocks to fill every CU at the occupancy the kernel's registers and LDS allow; surplus blocks are
+    // harmless (they start when a slot frees up and find the counter exhausted).
+    const uint32_t blocks = std::min<uint32_t>(n_cus * 8u, (plan.n_chunks + 3u) / 4u);
     // near-first traversal keeps at most (depth - 1) deferred children
-    if (tree_depth <= 24) return launch_stack<24>(sc, rp, d_rgb_sum, counters, stats, stream);
-    if (tree_depth <= 40) return launch_stack<40>(sc, rp, d_rgb_sum, counters, stats, stream);
-    if (tree_depth <= 64) return launch_stack<64>(sc, rp, d_rgb_sum, counters, stats, stream);
+    if (tree_depth <= 24) return launch_stack<24>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stats, stream);
+    if (tree_depth <= 40) return launch_stack<40>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stats, stream);
+    if (tree_depth <= 64) return launch_stack<64>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stats, stream);
     return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
 }
 

@@ -7,6 +7,8 @@
 #include "wavefront.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "device_rt.h"
@@ -230,6 +232,14 @@ hipError_t render_wavefront(WavefrontState& st, const DevScene& sc, const DevRen
             launches += 2;
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (getenv("RT_WF_DEBUG")) {  // queue length per bounce level of this batch
+            std::vector<uint32_t> host(levels + 1);
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            if ((e = hipMemcpy(host.data(), st.buf.counts, host.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+            fprintf(stderr, "[wavefront] batch @%u queue lengths:", first);
+            for (uint32_t v : host) fprintf(stderr, " %u", v);
+            fprintf(stderr, "\n");
+        }
     }
     *n_launches = launches;
     return hipSuccess;

@@ -33,3 +33,12 @@ Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s);
 void build_bvh(const rt_scene_desc& d, Bvh& out);
 
 }  // namespace rt
+
+namespace rt {
+
+// Render-path tree: the f32 kernels are free to use their own topology (only the f64 parity kernel and the
+// equal-t tie ranks need the reference's).  Binned SAH (32 bins, all three axes), scale-invariant cost,
+// leaves of at most `max_leaf` surfaces, built over the surface ids in `ids`.  `order` holds surface ids.
+void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out);
+
+}  // namespace rt

@@ -1,0 +1,131 @@
+// Binned-SAH BVH for the f32 render kernels (no reference counterpart: the reference traverses the tree of
+// bvh.rs:131-234, whose absolute traversal cost of 2.0 yields 30-90-triangle leaves on small-scale meshes such
+// as lucy.yaml; on a 64-lane machine short, uniform leaves matter more than build fidelity).
+#include <algorithm>
+#include <cmath>
+
+#include "bvh_build.h"
+
+namespace rt {
+
+namespace {
+
+constexpr int kBins = 32;
+constexpr double kTraversalCost = 1.0;  // relative to one primitive test
+constexpr double kIntersectCost = 1.0;
+
+struct Item {
+    Aabb box;
+    V3 c;
+    int32_t id;
+};
+
+double area(const Aabb& b) {
+    V3 l = b.hi - b.lo;
+    if (!(l.x >= 0 && l.y >= 0 && l.z >= 0)) return 0.0;
+    return 2.0 * (l.x * l.y + l.y * l.z + l.z * l.x);
+}
+
+struct RBuilder {
+    std::vector<Item> items;
+    Bvh* out;
+    uint32_t max_leaf;
+
+    int32_t leaf(size_t first, size_t n, const Aabb& box, uint32_t depth) {
+        BvhNode node;
+        node.box = box;
+        node.first = (int32_t)first, node.count = (int32_t)n;
+        out->nodes.push_back(node);
+        out->max_depth = std::max(out->max_depth, depth);
+        out->max_leaf_size = std::max(out->max_leaf_size, (uint32_t)n);
+        out->n_leaves++;
+        return (int32_t)out->nodes.size() - 1;
+    }
+
+    int32_t build(size_t first, size_t n, uint32_t depth) {
+        Aabb box = Aabb::empty(), cb = Aabb::empty();
+        for (size_t i = first; i < first + n; ++i) {
+            box = box.merge(items[i].box);
+            cb.lo = vmin(cb.lo, items[i].c), cb.hi = vmax(cb.hi, items[i].c);
+        }
+        if (n == 1) return leaf(first, n, box, depth);
+
+        double best_cost = INFINITY;
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            const double lo = cb.lo.get(axis), ext = cb.hi.get(axis) - lo;
+            if (!(ext > 0)) continue;
+            Aabb bb[kBins];
+            size_t cnt[kBins] = {0};
+            for (auto& b : bb) b = Aabb::empty();
+            const double scale = kBins / ext;
+            for (size_t i = first; i < first + n; ++i) {
+                int k = std::min(kBins - 1, (int)((items[i].c.get(axis) - lo) * scale));
+                cnt[k]++;
+                bb[k] = bb[k].merge(items[i].box);
+            }
+            double right_area[kBins];
+            size_t right_cnt[kBins];
+            Aabb acc = Aabb::empty();
+            size_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) {
+                acc = acc.merge(bb[k]);
+                c += cnt[k];
+                right_area[k] = area(acc), right_cnt[k] = c;
+            }
+            acc = Aabb::empty(), c = 0;
+            for (int k = 0; k + 1 < kBins; ++k) {
+                acc = acc.merge(bb[k]);
+                c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                double cost = area(acc) * (double)c + right_area[k + 1] * (double)right_cnt[k + 1];
+                if (cost < best_cost) best_cost = cost, best_axis = axis, best_bin = k;
+            }
+        }
+        const double parent_area = std::max(area(box), 1e-300);
+        const double split_cost = kTraversalCost + kIntersectCost * best_cost / parent_area;
+        const double leaf_cost = kIntersectCost * (double)n;
+        if (n <= max_leaf && (best_axis < 0 || leaf_cost <= split_cost)) return leaf(first, n, box, depth);
+
+        size_t mid;
+        if (best_axis < 0) {
+            mid = first + n / 2;  // coincident centroids: split by position in the list
+        } else {
+            const double lo = cb.lo.get(best_axis), scale = kBins / (cb.hi.get(best_axis) - lo);
+            auto it = std::partition(items.begin() + first, items.begin() + first + n, [&](const Item& it) {
+                return std::min(kBins - 1, (int)((it.c.get(best_axis) - lo) * scale)) <= best_bin;
+            });
+            mid = (size_t)(it - items.begin());
+            if (mid == first || mid == first + n) mid = first + n / 2;
+        }
+        const int32_t self = (int32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        const int32_t l = build(first, mid - first, depth + 1);
+        const int32_t r = build(mid, first + n - mid, depth + 1);
+        BvhNode& node = out->nodes[self];
+        node.left = l, node.right = r, node.box = box;
+        return self;
+    }
+};
+
+}  // namespace
+
+void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out) {
+    out = Bvh{};
+    RBuilder b;
+    b.out = &out;
+    b.max_leaf = std::max(1u, max_leaf);
+    b.items.resize(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) {
+        Aabb box = surface_bounds(d, d.surfaces[ids[i]]);
+        // a negative-radius sphere has an inverted box in the reference; the render tree needs a real one
+        Aabb fixed{vmin(box.lo, box.hi), vmax(box.lo, box.hi)};
+        b.items[i] = {fixed, 0.5 * (fixed.lo + fixed.hi), ids[i]};
+    }
+    out.nodes.reserve(ids.size());
+    if (!ids.empty()) b.build(0, ids.size(), 1);
+    out.order.resize(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) out.order[i] = b.items[i].id;
+}
+
+}  // namespace rt
