@@ -155,136 +155,167 @@ __device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double 
 // -1 is a miss.  Closest wins; an exact tie goes to the surface that comes later in the reference tree's
 // in-order leaf sequence (its "rank"), which is what the reference's recursion yields (bvh.rs:272-273, 308).
 //
+// The traversal is written as three steps — loose_hits (once per ray), node_step (one inner node),
+// prim_step (one leaf slot) — so that the wavefront `extend` kernel can run them as the classic
+// while-while loop (trace_closest) and the persistent kernel can schedule them stage by stage.
+//
 // `stack` points at this lane's column of an LDS array laid out [level][lane] (stride = block size), so
 // a push/pop is one conflict-free ds_write/ds_read.  The host checks tree depth <= stack levels.
-template <bool STATS>
-__device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& ray, float tmin, int* stack,
-                                                int stack_stride, TraceStats& st) {
-    HitRec best;
-    best.t = __builtin_inff();
-    best.slot = -1;
-    best.bu = best.bv = 0.f;
-    int best_rank = -1;
-    const D3 dd = d3(ray.d);
+constexpr int kTraversalDone = 0x7fffffff;  // "node" value once the stack has run empty
 
-    // ---- loose spheres/quads: every lane tests the same primitive at the same time (no divergence, the
-    // records come through the scalar cache); f64 because radius-1000 spheres and 555-unit walls need it
+struct Closest {
+    HitRec h;
+    int rank;  // rank of h.slot's surface (ties)
+};
+__device__ __forceinline__ void closest_reset(Closest& c) {
+    c.h.t = __builtin_inff();
+    c.h.slot = -1;
+    c.h.bu = c.h.bv = 0.f;
+    c.rank = -1;
+}
+
+// Loose spheres/quads: every lane tests the same primitive at the same time (no divergence, the records come
+// through the scalar cache); f64 because radius-1000 spheres and 555-unit walls need it.
+template <bool STATS>
+__device__ __forceinline__ void loose_hits(const DevScene& sc, const Ray& ray, float tmin, Closest& best, TraceStats& st) {
+    const D3 dd = d3(ray.d);
     for (uint32_t i = 0; i < sc.n_loose; ++i) {
         const int4 m = sc.loose[i];
         double t;
         if (m.x == 0) {
             if (STATS) st.spheres++;
-            t = sphere_root(sc.spheres + 4 * m.y, ray.o, dd, (double)tmin, (double)best.t);
+            t = sphere_root(sc.spheres + 4 * m.y, ray.o, dd, (double)tmin, (double)best.h.t);
         } else {
             if (STATS) st.quads++;
-            t = quad_root(sc.quads + 16 * m.y, ray.o, dd, (double)tmin, (double)best.t);
+            t = quad_root(sc.quads + 16 * m.y, ray.o, dd, (double)tmin, (double)best.h.t);
         }
         const float tf = (float)t;
-        if (tf >= tmin && (tf < best.t || (tf == best.t && m.z > best_rank))) {
-            best.t = tf, best.slot = -2 - (int)i, best_rank = m.z;
+        if (tf >= tmin && (tf < best.h.t || (tf == best.h.t && m.z > best.rank))) {
+            best.h.t = tf, best.h.slot = -2 - (int)i, best.rank = m.z;
         }
     }
-    if (!sc.has_tree) return best;
+}
 
-    const F3 o = tof(ray.o);
-    const F3 d = ray.d;
+struct SlabRay {  // f32 ray in the form the fma slab test wants
+    F3 o, d;
+    float idx, idy, idz, oodx, oody, oodz;
+};
+__device__ __forceinline__ SlabRay slab_ray(const Ray& ray) {
+    SlabRay r;
+    r.o = tof(ray.o);
+    r.d = ray.d;
     // A zero direction component would make lo*inf - o*inf a NaN or a wrongly signed infinity in the fma slab
-    // form below; clamp |d| away from zero (2^-80) so every slab bound stays finite and correctly ordered.
+    // form; clamp |d| away from zero (2^-80) so every slab bound stays finite and correctly ordered.
     const float ooeps = 0x1p-80f;
-    const float idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
-    const float idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
-    const float idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
-    const float oodx = o.x * idx, oody = o.y * idy, oodz = o.z * idz;
+    r.idx = __builtin_amdgcn_rcpf(fabsf(r.d.x) > ooeps ? r.d.x : copysignf(ooeps, r.d.x));
+    r.idy = __builtin_amdgcn_rcpf(fabsf(r.d.y) > ooeps ? r.d.y : copysignf(ooeps, r.d.y));
+    r.idz = __builtin_amdgcn_rcpf(fabsf(r.d.z) > ooeps ? r.d.z : copysignf(ooeps, r.d.z));
+    r.oodx = r.o.x * r.idx, r.oody = r.o.y * r.idy, r.oodz = r.o.z * r.idz;
+    return r;
+}
 
+__device__ __forceinline__ int stack_pop(int* stack, int stride, int& sp) {
+    if (sp == 0) return kTraversalDone;
+    --sp;
+    return stack[sp * stride];
+}
+
+// One inner node: test both children's boxes against [tmin, best_t], go to the nearer hit child, defer the
+// other.  Returns the next node (>= 0 inner, < 0 leaf ~first_slot, kTraversalDone).
+template <bool STATS>
+__device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, float tmin, float best_t, int node,
+                                         int* stack, int stride, int& sp, TraceStats& st) {
+    if (STATS) st.nodes++;
+    const float4 n0 = sc.nodes[4 * node + 0];
+    const float4 n1 = sc.nodes[4 * node + 1];
+    const float4 n2 = sc.nodes[4 * node + 2];
+    const float4 n3 = sc.nodes[4 * node + 3];
+    // child 0: lo = (n0.x n0.y n0.z) hi = (n0.w n1.x n1.y); child 1: lo = (n1.z n1.w n2.x) hi = (n2.y n2.z n2.w)
+    const float tmax_pad = best_t * 1.0000004f;
+    float ax = fmaf(n0.x, r.idx, -r.oodx), bx = fmaf(n0.w, r.idx, -r.oodx);
+    float ay = fmaf(n0.y, r.idy, -r.oody), by = fmaf(n1.x, r.idy, -r.oody);
+    float az = fmaf(n0.z, r.idz, -r.oodz), bz = fmaf(n1.y, r.idz, -r.oodz);
+    const float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
+    ax = fmaf(n1.z, r.idx, -r.oodx), bx = fmaf(n2.y, r.idx, -r.oodx);
+    ay = fmaf(n1.w, r.idy, -r.oody), by = fmaf(n2.z, r.idy, -r.oody);
+    az = fmaf(n2.x, r.idz, -r.oodz), bz = fmaf(n2.w, r.idz, -r.oodz);
+    const float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
+    const bool h0 = t0n <= t0f, h1 = t1n <= t1f;
+    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    if (h0 && h1) {
+        const bool swap = t1n < t0n;
+        stack[sp * stride] = swap ? c0 : c1;
+        ++sp;
+        return swap ? c1 : c0;
+    }
+    if (h0) return c0;
+    if (h1) return c1;
+    return stack_pop(stack, stride, sp);
+}
+
+// One leaf slot.  Returns true when it was the last slot of its leaf.
+template <bool STATS>
+__device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
+                                          Closest& best, TraceStats& st) {
+    const float4 p0 = sc.prims[3 * slot + 0];
+    const float4 p1 = sc.prims[3 * slot + 1];
+    const uint32_t meta = __float_as_uint(p0.w);
+    const uint32_t type = meta & kMetaTypeMask;
+    float t = -1.f, bu = 0.f, bv = 0.f;
+    if (type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
+        if (STATS) st.tris++;
+        const float4 p2 = sc.prims[3 * slot + 2];
+        const F3 e1 = f3(p1), e2 = f3(p2);
+        const F3 pvec = cross(r.d, e2);
+        const float det = dot(e1, pvec);
+        if (!(-1e-8f < det && det < 1e-8f)) {
+            const float inv_det = __builtin_amdgcn_rcpf(det);
+            const F3 tvec = r.o - f3(p0);
+            const float u = dot(tvec, pvec) * inv_det;
+            if (u >= 0.f && u <= 1.f) {
+                const F3 qvec = cross(tvec, e1);
+                const float v = dot(r.d, qvec) * inv_det;
+                if (!(v < 0.f || u + v > 1.f)) {
+                    const float tt = dot(e2, qvec) * inv_det;
+                    if (!(tt < 1e-4f) && tmin <= tt) t = tt, bu = u, bv = v;
+                }
+            }
+        }
+    } else if (type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
+        if (STATS) st.spheres++;
+        t = (float)sphere_root(sc.spheres + 4 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+    } else {
+        if (STATS) st.quads++;
+        t = (float)quad_root(sc.quads + 16 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+    }
+    if (t >= tmin && t <= best.h.t) {
+        const int rank = __float_as_int(p1.w);
+        if (t < best.h.t || rank > best.rank) best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank;
+    }
+    return (meta & kMetaLast) != 0u;
+}
+
+// The classic while-while loop over the steps (used by wf_extend and the f32 AOV kernel).
+template <bool STATS>
+__device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& ray, float tmin, int* stack,
+                                                int stack_stride, TraceStats& st) {
+    Closest best;
+    closest_reset(best);
+    loose_hits<STATS>(sc, ray, tmin, best, st);
+    if (!sc.has_tree) return best.h;
+    const SlabRay r = slab_ray(ray);
     int sp = 0;
     int node = 0;  // root is always an inner node (a single-leaf tree gets a synthetic root)
-    while (true) {
-        // ---- descend through inner nodes
-        while (node >= 0) {
-            if (STATS) st.nodes++;
-            const float4 n0 = sc.nodes[4 * node + 0];
-            const float4 n1 = sc.nodes[4 * node + 1];
-            const float4 n2 = sc.nodes[4 * node + 2];
-            const float4 n3 = sc.nodes[4 * node + 3];
-            // child 0: lo = (n0.x n0.y n0.z) hi = (n0.w n1.x n1.y); child 1: lo = (n1.z n1.w n2.x) hi = (n2.y n2.z n2.w)
-            const float tmax_pad = best.t * 1.0000004f;
-            float ax = fmaf(n0.x, idx, -oodx), bx = fmaf(n0.w, idx, -oodx);
-            float ay = fmaf(n0.y, idy, -oody), by = fmaf(n1.x, idy, -oody);
-            float az = fmaf(n0.z, idz, -oodz), bz = fmaf(n1.y, idz, -oodz);
-            float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-            float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
-            ax = fmaf(n1.z, idx, -oodx), bx = fmaf(n2.y, idx, -oodx);
-            ay = fmaf(n1.w, idy, -oody), by = fmaf(n2.z, idy, -oody);
-            az = fmaf(n2.x, idz, -oodz), bz = fmaf(n2.w, idz, -oodz);
-            float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-            float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
-            const bool h0 = t0n <= t0f, h1 = t1n <= t1f;
-            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            if (h0 && h1) {
-                const bool swap = t1n < t0n;
-                const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                stack[sp * stack_stride] = farc;
-                ++sp;
-                node = nearc;
-            } else if (h0) {
-                node = c0;
-            } else if (h1) {
-                node = c1;
-            } else {
-                if (sp == 0) return best;
-                --sp;
-                node = stack[sp * stack_stride];
-            }
-        }
-        // ---- leaf: scan slots until the last-in-leaf flag
+    while (node != kTraversalDone) {
+        while (node >= 0 && node != kTraversalDone) node = node_step<STATS>(sc, r, tmin, best.h.t, node, stack, stack_stride, sp, st);
+        if (node == kTraversalDone) break;
         int slot = ~node;
-        while (true) {
-            const float4 p0 = sc.prims[3 * slot + 0];
-            const float4 p1 = sc.prims[3 * slot + 1];
-            const uint32_t meta = __float_as_uint(p0.w);
-            const uint32_t type = meta & kMetaTypeMask;
-            float t = -1.f, bu = 0.f, bv = 0.f;
-            if (type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
-                if (STATS) st.tris++;
-                const float4 p2 = sc.prims[3 * slot + 2];
-                const F3 e1 = f3(p1), e2 = f3(p2);
-                const F3 pvec = cross(d, e2);
-                const float det = dot(e1, pvec);
-                if (!(-1e-8f < det && det < 1e-8f)) {
-                    const float inv_det = __builtin_amdgcn_rcpf(det);
-                    const F3 tvec = o - f3(p0);
-                    const float u = dot(tvec, pvec) * inv_det;
-                    if (u >= 0.f && u <= 1.f) {
-                        const F3 qvec = cross(tvec, e1);
-                        const float v = dot(d, qvec) * inv_det;
-                        if (!(v < 0.f || u + v > 1.f)) {
-                            const float tt = dot(e2, qvec) * inv_det;
-                            if (!(tt < 1e-4f) && tmin <= tt) {
-                                t = tt, bu = u, bv = v;
-                            }
-                        }
-                    }
-                }
-            } else if (type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
-                if (STATS) st.spheres++;
-                t = (float)sphere_root(sc.spheres + 4 * (meta >> kMetaIndexShift), ray.o, dd, (double)tmin, (double)best.t);
-            } else {
-                if (STATS) st.quads++;
-                t = (float)quad_root(sc.quads + 16 * (meta >> kMetaIndexShift), ray.o, dd, (double)tmin, (double)best.t);
-            }
-            if (t >= tmin && t <= best.t) {
-                const int rank = __float_as_int(p1.w);
-                if (t < best.t || rank > best_rank) {
-                    best.t = t, best.slot = slot, best.bu = bu, best.bv = bv, best_rank = rank;
-                }
-            }
-            if (meta & kMetaLast) break;
-            ++slot;
-        }
-        if (sp == 0) return best;
-        --sp;
-        node = stack[sp * stack_stride];
+        while (!prim_step<STATS>(sc, ray, r, tmin, slot, best, st)) ++slot;
+        node = stack_pop(stack, stack_stride, sp);
     }
+    return best.h;
 }
 
 // ---------------------------------------------------------------- shading

@@ -26,6 +26,12 @@ struct PersistentPlan {
     uint32_t n_chunks;       // n_tiles * groups
 };
 
+// Lane stages, encoded in `node`: an inner node id (>= 0) = one node_step pending; a leaf reference (< 0,
+// ~slot) = one prim_step pending; kStageShade = the trace is complete (or no path yet): shade / regenerate /
+// start the next trace; kStageIdle = no path and no work left.
+constexpr int kStageShade = kTraversalDone;
+constexpr int kStageIdle = 0x7ffffffe;
+
 template <int STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ rgb_sum,
@@ -40,68 +46,108 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
     uint32_t chunk_tile = 0, chunk_group = 0, next_j = 0, chunk_total = 0;
     bool exhausted = false;
 
-    // per-lane path state
+    // per-lane path + traversal state
     F3 lsum = {0.f, 0.f, 0.f}, thr = {1.f, 1.f, 1.f};
     Ray ray;
     ray.o = {0., 0., 0.};
     ray.d = {0.f, 0.f, 1.f};
+    SlabRay sr = slab_ray(ray);
+    Closest best;
+    closest_reset(best);
     Rng rng;
     rng.s = 0;
     uint32_t depth = 0, pix = 0;
-    bool alive = false;
+    bool alive = false;   // a path is in flight
+    int node = kStageShade;
+    int sp = 0;
     TraceStats st;
     uint32_t n_segments = 0;
 
+    // Every trip runs ONE stage for the lanes waiting in it — the stage most lanes wait in — so the lanes that
+    // execute a trip all do the same small piece of work (one node, one primitive, or one shade+raygen),
+    // whatever mix of cheap sky/ground rays and long mesh traversals the wave holds.
     while (true) {
-        // ---- refill: lanes without a path take the next samples of the chunk (uniform control flow)
-        unsigned long long need = __ballot(!alive);
-        while (need != 0ull && !exhausted) {
-            if (next_j >= chunk_total) {
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(work_counter, 1u);
-                c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= plan.n_chunks) {
-                    exhausted = true;
-                    break;
-                }
-                // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
-                chunk_group = c / plan.n_tiles;
-                chunk_tile = c - chunk_group * plan.n_tiles;
-                const uint32_t strata_here = min(kChunkStrata, plan.my_strata - chunk_group * kChunkStrata);
-                chunk_total = 64u * strata_here;
-                next_j = 0;
-            }
-            const uint32_t avail = chunk_total - next_j;
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (!alive && before < avail) {
-                const uint32_t j = next_j + before;
-                const uint32_t in_tile = j & 63u;
-                const uint32_t px = (chunk_tile % plan.tiles_x) * 8u + (in_tile & 7u);
-                const uint32_t py = (chunk_tile / plan.tiles_x) * 8u + (in_tile >> 3);  // image row, 0 = top
-                if (px < rp.width && py < rp.height) {
-                    const uint32_t stratum = rp.stratum_begin + (chunk_group * kChunkStrata + (j >> 6)) * rp.stratum_step;
-                    pix = py * rp.width + px;  // == the reference's idx: pi = idx % W, pj = H - idx/W - 1
-                    rng_init(rng, seed, pix, stratum);
-                    ray = camera_ray(sc, rp, px, rp.height - py - 1u, stratum, rng);
-                    thr = {1.f, 1.f, 1.f};
-                    lsum = {0.f, 0.f, 0.f};
-                    depth = 0;
-                    alive = true;
-                }
-            }
-            next_j += min((uint32_t)__popcll(need), avail);
-            need = __ballot(!alive);
-        }
-        if (__ballot(alive) == 0ull) break;  // nothing in flight and no work left
+        const unsigned long long m_shade = __ballot(node == kStageShade);
+        const unsigned long long m_leaf = __ballot(node < 0);
+        const unsigned long long m_node = __ballot(node >= 0 && node < kStageIdle);
+        const int n_shade = __popcll(m_shade), n_leaf = __popcll(m_leaf), n_node = __popcll(m_node);
+        if ((n_shade | n_leaf | n_node) == 0) break;  // every lane idle: no paths in flight, no work left
 
-        if (alive) {
-            const HitRec hit = trace_closest<STATS>(sc, ray, 0.001f, stack, kBlock, st);  // scene/mod.rs:104
-            if (STATS) n_segments++;
-            alive = shade_bounce(sc, ray, hit, 0.001f, rng, thr, lsum, depth, rp.max_depth);
-            if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
-                atomicAdd(&rgb_sum[3 * pix + 0], lsum.x);
-                atomicAdd(&rgb_sum[3 * pix + 1], lsum.y);
-                atomicAdd(&rgb_sum[3 * pix + 2], lsum.z);
+        if (n_node >= n_leaf && n_node >= n_shade) {
+            if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, kBlock, sp, st);
+        } else if (n_leaf >= n_shade) {
+            if (node < 0) {
+                const int slot = ~node;
+                const bool last = prim_step<STATS>(sc, ray, sr, 0.001f, slot, best, st);
+                node = last ? stack_pop(stack, kBlock, sp) : ~(slot + 1);
+            }
+        } else {
+            const bool mine = node == kStageShade;
+            // ---- shade the finished segment (scene/mod.rs:104-123)
+            if (mine && alive) {
+                alive = shade_bounce(sc, ray, best.h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+                if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
+                    atomicAdd(&rgb_sum[3 * pix + 0], lsum.x);
+                    atomicAdd(&rgb_sum[3 * pix + 1], lsum.y);
+                    atomicAdd(&rgb_sum[3 * pix + 2], lsum.z);
+                }
+            }
+            // ---- regenerate: lanes without a path take the next samples of the chunk (uniform control flow)
+            unsigned long long need = __ballot(mine && !alive);
+            while (need != 0ull && !exhausted) {
+                if (next_j >= chunk_total) {
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(work_counter, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c);
+                    if (c >= plan.n_chunks) {
+                        exhausted = true;
+                        break;
+                    }
+                    // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
+                    chunk_group = c / plan.n_tiles;
+                    chunk_tile = c - chunk_group * plan.n_tiles;
+                    const uint32_t strata_here = min(kChunkStrata, plan.my_strata - chunk_group * kChunkStrata);
+                    chunk_total = 64u * strata_here;
+                    next_j = 0;
+                }
+                const uint32_t avail = chunk_total - next_j;
+                const uint32_t before =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                if (mine && !alive && before < avail) {
+                    const uint32_t j = next_j + before;
+                    const uint32_t in_tile = j & 63u;
+                    const uint32_t px = (chunk_tile % plan.tiles_x) * 8u + (in_tile & 7u);
+                    const uint32_t py = (chunk_tile / plan.tiles_x) * 8u + (in_tile >> 3);  // image row, 0 = top
+                    if (px < rp.width && py < rp.height) {
+                        const uint32_t stratum =
+                            rp.stratum_begin + (chunk_group * kChunkStrata + (j >> 6)) * rp.stratum_step;
+                        pix = py * rp.width + px;  // == the reference's idx: pi = idx % W, pj = H - idx/W - 1
+                        rng_init(rng, seed, pix, stratum);
+                        ray = camera_ray(sc, rp, px, rp.height - py - 1u, stratum, rng);
+                        thr = {1.f, 1.f, 1.f};
+                        lsum = {0.f, 0.f, 0.f};
+                        depth = 0;
+                        alive = true;
+                    }
+                }
+                next_j += min((uint32_t)__popcll(need), avail);
+                need = __ballot(mine && !alive);
+            }
+            // ---- start the next segment's trace: loose spheres/quads now (all these lanes in lockstep), the
+            // tree through the node/leaf stages
+            if (mine) {
+                if (alive) {
+                    if (STATS) n_segments++;
+                    closest_reset(best);
+                    loose_hits<STATS>(sc, ray, 0.001f, best, st);
+                    if (sc.has_tree) {
+                        sr = slab_ray(ray);
+                        sp = 0;
+                        node = 0;
+                    }  // else: the trace is already complete; stay in the shade stage
+                } else {
+                    node = kStageIdle;
+                }
             }
         }
     }
