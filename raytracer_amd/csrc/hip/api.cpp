@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -72,6 +74,7 @@ struct rt_scene {
     Bvh bvh;         // reference topology (bvh.rs:131-234): parity kernel + tie ranks
     Bvh render_bvh;  // binned-SAH tree the f32 render kernels traverse
     bool has_tree = false;
+    float tree_lo[3] = {0, 0, 0}, tree_hi[3] = {0, 0, 0};
     rt_scene_info info{};
     uint32_t stack_depth = 0;  // depth of the flattened render tree incl. a synthetic root
     uint32_t n_cus = 256;
@@ -282,6 +285,10 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         }
     };
     s.stack_depth = 2;
+    for (int a = 0; a < 3; ++a) {
+        s.tree_lo[a] = s.has_tree ? round_down(rb.nodes[0].box.lo.get(a) - inflate) : 1e30f;
+        s.tree_hi[a] = s.has_tree ? round_up(rb.nodes[0].box.hi.get(a) + inflate) : 1e30f;
+    }
     if (s.has_tree && ft.root_is_leaf) {
         // synthetic root: child 0 = the leaf; child 1 = a far-away point box over one dummy slot (a
         // degenerate triangle) that can never be hit
@@ -454,6 +461,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.n_slots = (uint32_t)s->slot_surface.size();
         s->dev.n_loose = (uint32_t)s->loose.size();
         s->dev.has_tree = s->has_tree ? 1u : 0u;
+        for (int a = 0; a < 3; ++a) s->dev.tree_lo[a] = s->tree_lo[a], s->dev.tree_hi[a] = s->tree_hi[a];
         if (device == RT_DEVICE_NONE) {
             s->device = -1;
             *out = s.release();
@@ -542,6 +550,10 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                 HIP_CHECK(hipMemcpy(&c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
                 stats->segments = c.segments, stats->node_visits = c.node_visits, stats->tri_tests = c.tri_tests;
                 stats->sphere_tests = c.sphere_tests, stats->quad_tests = c.quad_tests;
+                if (getenv("RT_STAGE_DEBUG"))
+                    for (int k = 0; k < 3; ++k)
+                        fprintf(stderr, "[stages] %d: trips %llu lanes/trip %.1f\n", k, c.stage_trips[k],
+                                c.stage_trips[k] ? (double)c.stage_lanes[k] / (double)c.stage_trips[k] : 0.0);
             }
         }
         return 0;

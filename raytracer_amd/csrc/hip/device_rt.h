@@ -94,6 +94,16 @@ struct HitRec {
     float bu, bv;  // triangle barycentrics
 };
 
+// Sphere/quad hits keep their f64 root in the (otherwise unused) barycentric slots, so the shade step can
+// place the hit point on the surface without repeating the intersection.
+__device__ __forceinline__ void hit_set_t64(HitRec& h, double t) {
+    h.bu = __int_as_float(__double2loint(t));
+    h.bv = __int_as_float(__double2hiint(t));
+}
+__device__ __forceinline__ double hit_get_t64(const HitRec& h) {
+    return __hiloint2double(__float_as_int(h.bv), __float_as_int(h.bu));
+}
+
 struct TraceStats {
     uint32_t nodes = 0, tris = 0, spheres = 0, quads = 0;
 };
@@ -192,6 +202,7 @@ __device__ __forceinline__ void loose_hits(const DevScene& sc, const Ray& ray, f
         const float tf = (float)t;
         if (tf >= tmin && (tf < best.h.t || (tf == best.h.t && m.z > best.rank))) {
             best.h.t = tf, best.h.slot = -2 - (int)i, best.rank = m.z;
+            hit_set_t64(best.h, t);
         }
     }
 }
@@ -212,6 +223,17 @@ __device__ __forceinline__ SlabRay slab_ray(const Ray& ray) {
     r.idz = __builtin_amdgcn_rcpf(fabsf(r.d.z) > ooeps ? r.d.z : copysignf(ooeps, r.d.z));
     r.oodx = r.o.x * r.idx, r.oody = r.o.y * r.idy, r.oodz = r.o.z * r.idz;
     return r;
+}
+
+// Does the ray reach the render tree's bounds at all within [tmin, best_t]?  Most sky/ground rays do not, and
+// then skip the traversal stages entirely.
+__device__ __forceinline__ bool hits_tree_bounds(const DevScene& sc, const SlabRay& r, float tmin, float best_t) {
+    const float ax = fmaf(sc.tree_lo[0], r.idx, -r.oodx), bx = fmaf(sc.tree_hi[0], r.idx, -r.oodx);
+    const float ay = fmaf(sc.tree_lo[1], r.idy, -r.oody), by = fmaf(sc.tree_hi[1], r.idy, -r.oody);
+    const float az = fmaf(sc.tree_lo[2], r.idz, -r.oodz), bz = fmaf(sc.tree_hi[2], r.idz, -r.oodz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t * 1.0000004f));
+    return tn <= tf;
 }
 
 __device__ __forceinline__ int stack_pop(int* stack, int stride, int& sp) {
@@ -264,6 +286,7 @@ __device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, co
     const uint32_t meta = __float_as_uint(p0.w);
     const uint32_t type = meta & kMetaTypeMask;
     float t = -1.f, bu = 0.f, bv = 0.f;
+    double t64 = -1.0;
     if (type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
         if (STATS) st.tris++;
         const float4 p2 = sc.prims[3 * slot + 2];
@@ -285,14 +308,19 @@ __device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, co
         }
     } else if (type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
         if (STATS) st.spheres++;
-        t = (float)sphere_root(sc.spheres + 4 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+        t64 = sphere_root(sc.spheres + 4 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+        t = (float)t64;
     } else {
         if (STATS) st.quads++;
-        t = (float)quad_root(sc.quads + 16 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+        t64 = quad_root(sc.quads + 16 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+        t = (float)t64;
     }
     if (t >= tmin && t <= best.h.t) {
         const int rank = __float_as_int(p1.w);
-        if (t < best.h.t || rank > best.rank) best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank;
+        if (t < best.h.t || rank > best.rank) {
+            best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank;
+            if (type != 1u) hit_set_t64(best.h, t64);
+        }
     }
     return (meta & kMetaLast) != 0u;
 }
@@ -307,7 +335,7 @@ __device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& r
     if (!sc.has_tree) return best.h;
     const SlabRay r = slab_ray(ray);
     int sp = 0;
-    int node = 0;  // root is always an inner node (a single-leaf tree gets a synthetic root)
+    int node = hits_tree_bounds(sc, r, tmin, best.h.t) ? 0 : kTraversalDone;  // the root is always an inner node
     while (node != kTraversalDone) {
         while (node >= 0 && node != kTraversalDone) node = node_step<STATS>(sc, r, tmin, best.h.t, node, stack, stack_stride, sp, st);
         if (node == kTraversalDone) break;
@@ -352,17 +380,13 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
         p = ray.o + (double)hit.t * dd;
     } else if (type == 0u) {
         const double* spd = sc.spheres + 4 * index;
-        double t = sphere_root(spd, ray.o, dd, (double)tmin, __builtin_inf());  // the f64 root (hit.t is rounded)
-        if (t < 0.0) t = (double)hit.t;
-        p = ray.o + t * dd;
+        p = ray.o + hit_get_t64(hit) * dd;  // the f64 root (hit.t is its f32 rounding)
         D3 nn = (1.0 / spd[3]) * (p - d3(spd));  // signed radius: a negative one flips the normal
         n = tof(nn);
         mat = sc.sphere_mat[index];
     } else {
         const double* qd = sc.quads + 16 * index;
-        double t = quad_root(qd, ray.o, dd, (double)tmin, __builtin_inf());
-        if (t < 0.0) t = (double)hit.t;
-        p = ray.o + t * dd;
+        p = ray.o + hit_get_t64(hit) * dd;
         n = tof(d3(qd));
         mat = sc.quad_mat[index];
     }

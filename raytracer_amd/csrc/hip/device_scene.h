@@ -43,6 +43,7 @@ struct DevScene {
     const int4* loose;          // spheres/quads tested by every ray before traversal: type, index, rank, surface id
     uint32_t n_loose;
     uint32_t has_tree;          // 0: no surface lives in the render tree (all are loose)
+    float tree_lo[3], tree_hi[3];  // bounds of the render tree (inflated like the node boxes)
     const double* spheres;      // 4 per sphere: c.xyz r
     const double* quads;        // 16 per quad: normal(3) d q(3) A=v×w (3) B=w×u (3) pad(3)
     const int32_t* sphere_mat;  // material id per sphere
@@ -69,6 +70,7 @@ struct DevCounters {  // one instance in HBM, bumped with one atomic per wave at
     unsigned long long samples, segments, node_visits, tri_tests, sphere_tests, quad_tests;
     unsigned int work;  // chunk cursor of the persistent kernel
     unsigned int pad;
+    unsigned long long stage_trips[8], stage_lanes[8];  // persistent kernel, counting build: per stage
 };
 
 }  // namespace rt

@@ -10,6 +10,7 @@
 // exactly once (at a light, at the sky, or nothing), so that is 12 B of atomic traffic per sample and the
 // only HBM traffic besides scene fetches.
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_rt.h"
 #include "kernels.h"
@@ -20,6 +21,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kChunkStrata = 16;  // strata per chunk (a chunk is 64 pixels x this many strata)
 
 struct PersistentPlan {
+    int shade_threshold;     // run the shade stage once this many lanes wait in it (or nothing else can run)
     uint32_t tiles_x, n_tiles;
     uint32_t my_strata;      // strata this call renders (begin, begin+step, ...)
     uint32_t groups;         // ceil(my_strata / kChunkStrata)
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
     int sp = 0;
     TraceStats st;
     uint32_t n_segments = 0;
+    uint32_t trips[3] = {0, 0, 0}, lanes_on[3] = {0, 0, 0};  // counting build: stage occupancy
 
     // Every trip runs ONE stage for the lanes waiting in it — the stage most lanes wait in — so the lanes that
     // execute a trip all do the same small piece of work (one node, one primitive, or one shade+raygen),
@@ -73,15 +76,19 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
         const int n_shade = __popcll(m_shade), n_leaf = __popcll(m_leaf), n_node = __popcll(m_node);
         if ((n_shade | n_leaf | n_node) == 0) break;  // every lane idle: no paths in flight, no work left
 
-        if (n_node >= n_leaf && n_node >= n_shade) {
+        const bool run_shade = n_shade >= plan.shade_threshold || (n_node | n_leaf) == 0;
+        if (!run_shade && n_node >= n_leaf) {
+            if (STATS) trips[0]++, lanes_on[0] += n_node;
             if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, kBlock, sp, st);
-        } else if (n_leaf >= n_shade) {
+        } else if (!run_shade) {
+            if (STATS) trips[1]++, lanes_on[1] += n_leaf;
             if (node < 0) {
-                const int slot = ~node;
-                const bool last = prim_step<STATS>(sc, ray, sr, 0.001f, slot, best, st);
-                node = last ? stack_pop(stack, kBlock, sp) : ~(slot + 1);
+                int slot = ~node;  // leaves hold at most 4 slots (render tree), so the whole leaf is one trip
+                while (!prim_step<STATS>(sc, ray, sr, 0.001f, slot, best, st)) ++slot;
+                node = stack_pop(stack, kBlock, sp);
             }
         } else {
+            if (STATS) trips[2]++, lanes_on[2] += n_shade;
             const bool mine = node == kStageShade;
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
@@ -143,8 +150,9 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
                     if (sc.has_tree) {
                         sr = slab_ray(ray);
                         sp = 0;
-                        node = 0;
-                    }  // else: the trace is already complete; stay in the shade stage
+                        // rays that never reach the tree's bounds are complete already: stay in the shade stage
+                        node = hits_tree_bounds(sc, sr, 0.001f, best.h.t) ? 0 : kStageShade;
+                    }
                 } else {
                     node = kStageIdle;
                 }
@@ -158,6 +166,11 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
         atomicAdd(&counters->tri_tests, (unsigned long long)st.tris);
         atomicAdd(&counters->sphere_tests, (unsigned long long)st.spheres);
         atomicAdd(&counters->quad_tests, (unsigned long long)st.quads);
+        if (lane == 0)
+            for (int k = 0; k < 3; ++k) {
+                atomicAdd(&counters->stage_trips[k], (unsigned long long)trips[k]);
+                atomicAdd(&counters->stage_lanes[k], (unsigned long long)lanes_on[k]);
+            }
     }
 }
 
@@ -178,6 +191,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
                                     uint32_t n_cus, float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter,
                                     bool stats, hipStream_t stream) {
     PersistentPlan plan;
+    plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T")) : 40;
     plan.tiles_x = (rp.width + 7u) >> 3;
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
     plan.my_strata =
