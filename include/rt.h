@@ -136,6 +136,10 @@ int rt_scene_leaf_order(const rt_scene* scene, int32_t* out_surface_ids);
 /* ---- the hot path: replaces the pixel loop main.rs:150-185 ---- */
 
 enum { RT_KERNEL_PERSISTENT = 0, RT_KERNEL_WAVEFRONT = 1 };
+/* How unit-sphere / unit-disk samples are drawn (util.rs:15-35).  Same distributions:
+ *   REFERENCE: the reference's rejection loops, in its draw order;
+ *   DIRECT:    closed-form maps with a fixed number of draws (no data-dependent loop on the GPU). */
+enum { RT_SAMPLER_REFERENCE = 0, RT_SAMPLER_DIRECT = 1 };
 
 typedef struct rt_render_params {
     uint32_t width, height;
@@ -146,6 +150,8 @@ typedef struct rt_render_params {
     uint32_t stratum_step;   /* (k = si*sn + sj, main.rs:165-166); 0 is treated as 1          */
     int32_t kernel;          /* RT_KERNEL_* */
     int32_t collect_stats;   /* non-zero: count node visits / primitive tests (slower build of the kernel) */
+    int32_t sampler;         /* RT_SAMPLER_* */
+    int32_t _pad;
 } rt_render_params;
 
 typedef struct rt_stats {

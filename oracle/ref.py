@@ -29,7 +29,8 @@ def lib():
         L.ref_camera.argtypes = [vp, dp]
         L.ref_primary_hits.argtypes = [vp, C.c_uint32, C.c_uint32, dp, dp, C.c_int]
         L.ref_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
-                                 C.c_uint32, C.c_int, dp, dp]
+                                 C.c_uint32, C.c_int, dp, dp, C.c_int]
+        L.ref_sample.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, dp]
         L.ref_tonemap.argtypes = [dp, C.c_size_t, C.c_double, dp]
         L.ref_aabb_surface_area.restype = C.c_double
         L.ref_aabb_surface_area.argtypes = [dp, dp]
@@ -103,11 +104,13 @@ class RefScene:
         lib().ref_primary_hits(self._h, width, height, _p(ids), _p(t), threads)
         return ids, t
 
-    def render(self, width, height, sn, max_depth=40, seed=1, stratum_begin=0, stratum_step=1, threads=8):
+    def render(self, width, height, sn, max_depth=40, seed=1, stratum_begin=0, stratum_step=1, threads=8,
+               sampler=0):
+        """sampler 0 = the reference's rejection loops (util.rs:15-35), 1 = the equal-distribution direct maps."""
         out = np.empty((height, width, 3), dtype=np.float64)
         cnt = np.zeros(5, dtype=np.uint64)
         lib().ref_render(self._h, width, height, sn, max_depth, seed, stratum_begin, stratum_step, threads, _p(out),
-                         _p(cnt))
+                         _p(cnt), sampler)
         names = ["box_tests", "tri_tests", "sphere_tests", "quad_tests", "segments"]
         return out, {n: int(c) for n, c in zip(names, cnt)}
 
@@ -130,6 +133,13 @@ def scatter(kind, albedo, param, direction, normal, front_face, rng_state):
     a, d, n, out = _d(albedo), _d(direction), _d(normal), np.zeros(6)
     ok = lib().ref_scatter(kind, _p(a), param, _p(d), _p(n), 1 if front_face else 0, rng_state, _p(out))
     return (out[:3].copy(), out[3:].copy()) if ok else None
+
+
+def sample(which, sampler, state, n):
+    """which: 0 in_unit_sphere, 1 unit(in_unit_sphere), 2 in_unit_disk."""
+    out = np.zeros((n, 3))
+    lib().ref_sample(which, sampler, state, n, _p(out))
+    return out
 
 
 def rng_stream(seed, pixel, stratum, n):

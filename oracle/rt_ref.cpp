@@ -79,8 +79,24 @@ inline uint32_t rng_next(Rng& r) {
 inline double gen_f64(Rng& r) { return (double)(rng_next(r) >> 8) * 0x1p-24; }  // stands in for rng.gen::<f64>()
 inline double gen_pm1(Rng& r) { return gen_f64(r) * 2.0 - 1.0; }                // stands in for Uniform::new(-1,1)
 
+// Sampler 1 ("direct"): closed-form maps with the same distributions as the rejection loops of util.rs:15-35
+// and a fixed number of draws.  NOT in the reference — it is the GPU's loop-free sampler
+// (RT_SAMPLER_DIRECT), restated here so that mode can be compared path by path as well;
+// tests/test_oracle_kat.py checks that both samplers give the same distribution and images.
+const double TWO_PI = 6.283185307179586476925286766559;
+inline Vec3 direct_unit_vector(Rng& r) {
+    double z = 1.0 - 2.0 * gen_f64(r);
+    double turn = gen_f64(r);
+    double rad = std::sqrt(std::fmax(0.0, 1.0 - z * z));
+    return {rad * std::cos(TWO_PI * turn), rad * std::sin(TWO_PI * turn), z};
+}
+
 // util.rs:15-24
-inline Vec3 gen_in_unit_sphere(Rng& r) {
+inline Vec3 gen_in_unit_sphere(Rng& r, int sampler = 0) {
+    if (sampler == 1) {
+        Vec3 u = direct_unit_vector(r);
+        return std::cbrt(gen_f64(r)) * u;
+    }
     while (true) {
         double x = gen_pm1(r), y = gen_pm1(r), z = gen_pm1(r);  // Vec3::rand_within, geom.rs:196-198
         Vec3 v{x, y, z};
@@ -88,7 +104,12 @@ inline Vec3 gen_in_unit_sphere(Rng& r) {
     }
 }
 // util.rs:26-35
-inline Vec3 gen_in_unit_disk(Rng& r) {
+inline Vec3 gen_in_unit_disk(Rng& r, int sampler = 0) {
+    if (sampler == 1) {
+        double rad = std::sqrt(gen_f64(r));
+        double turn = gen_f64(r);
+        return {rad * std::cos(TWO_PI * turn), rad * std::sin(TWO_PI * turn), 0.0};
+    }
     while (true) {
         double x = gen_pm1(r), y = gen_pm1(r);
         Vec3 v{x, y, 0.0};
@@ -192,17 +213,18 @@ inline double reflectance(double cosine, double refractive_index) {  // material
 }
 
 // Material::scatter, material.rs:59-64 / 86-159.  Returns false for "None".
-inline bool scatter(const Material& m, const Ray& ray, const Hit& hit, Rng& rng, Vec3& attenuation, Ray& out) {
+inline bool scatter(const Material& m, const Ray& ray, const Hit& hit, Rng& rng, Vec3& attenuation, Ray& out,
+                    int sampler = 0) {
     switch (m.kind) {
         case Lambertian: {  // material.rs:100-118
-            Vec3 dir = hit.normal + unit(gen_in_unit_sphere(rng));
+            Vec3 dir = hit.normal + (sampler == 1 ? direct_unit_vector(rng) : unit(gen_in_unit_sphere(rng)));
             if (near_zero(dir)) dir = hit.normal;
             out = Ray(hit.point, dir, ray.time);
             break;
         }
         case Metal: {  // material.rs:126-138
             Vec3 reflected = reflect(ray.dir, hit.normal);
-            Ray scattered(hit.point, reflected + m.param * gen_in_unit_sphere(rng), ray.time);
+            Ray scattered(hit.point, reflected + m.param * gen_in_unit_sphere(rng, sampler), ray.time);
             if (!(dot(scattered.dir, hit.normal) > 1e-8)) return false;
             out = scattered;
             break;
@@ -470,8 +492,8 @@ struct Camera {
         return c;
     }
     // camera.rs:76-87
-    Ray get_ray(Rng& rng, double u, double v) const {
-        Vec3 rd = lens_radius * gen_in_unit_disk(rng);
+    Ray get_ray(Rng& rng, double u, double v, int sampler = 0) const {
+        Vec3 rd = lens_radius * gen_in_unit_disk(rng, sampler);
         Vec3 offset = bu * rd.x + bv * rd.y;
         Vec3 offset_origin = origin - offset;
         double ray_time = gen_f64(rng);  // gen_range(0.0..1.0)
@@ -488,7 +510,8 @@ struct Scene {
     size_t n_surfaces = 0;
 
     // ray_color_impl + resolve_color, scene/mod.rs:86-135 (the no-scatter case re-traces the same ray: Q1)
-    Vec3 ray_color(Ray ray, Rng& rng, size_t max_depth, std::vector<std::pair<Vec3, Vec3>>& stack, Counters& c) const {
+    Vec3 ray_color(Ray ray, Rng& rng, size_t max_depth, std::vector<std::pair<Vec3, Vec3>>& stack, Counters& c,
+                   int sampler = 0) const {
         stack.clear();
         size_t depth = 0;
         while (true) {
@@ -499,7 +522,7 @@ struct Scene {
                 Vec3 emitted = emit(*hit.material);
                 Vec3 att;
                 Ray scattered;
-                if (scatter(*hit.material, ray, hit, rng, att, scattered)) {
+                if (scatter(*hit.material, ray, hit, rng, att, scattered, sampler)) {
                     stack.push_back({emitted, att});
                     ray = scattered;
                 }
@@ -646,7 +669,8 @@ void ref_primary_hits(void* h, uint32_t width, uint32_t height, int32_t* prim_id
 // The pixel loop main.rs:150-185 for strata k = begin, begin+step, ... < sn*sn.  rgb_sum: 3*W*H doubles,
 // un-normalised sums, row 0 = top.  counters5: box tests, tri, sphere, quad tests, segments.
 void ref_render(void* h, uint32_t width, uint32_t height, uint32_t sn, uint32_t max_depth, uint64_t seed,
-                uint32_t stratum_begin, uint32_t stratum_step, int threads, double* rgb_sum, uint64_t* counters5) {
+                uint32_t stratum_begin, uint32_t stratum_step, int threads, double* rgb_sum, uint64_t* counters5,
+                int sampler) {
     const Scene* sc = (const Scene*)h;
     if (stratum_step == 0) stratum_step = 1;
     const double recip_sn = 1.0 / (double)sn;
@@ -670,8 +694,8 @@ void ref_render(void* h, uint32_t width, uint32_t height, uint32_t sn, uint32_t 
                     double jitterv = -0.5 + recip_sn * ((double)sj + gen_f64(rng));
                     double u = centeru + jitteru * pixel_du;
                     double v = centerv + jitterv * pixel_dv;
-                    Ray ray = sc->camera.get_ray(rng, u, v);
-                    Vec3 col3 = sc->ray_color(ray, rng, max_depth, stack, c);
+                    Ray ray = sc->camera.get_ray(rng, u, v, sampler);
+                    Vec3 col3 = sc->ray_color(ray, rng, max_depth, stack, c, sampler);
                     acc = acc + col3;
                 }
                 rgb_sum[3 * idx] = acc.x, rgb_sum[3 * idx + 1] = acc.y, rgb_sum[3 * idx + 2] = acc.z;
@@ -751,6 +775,16 @@ int ref_scatter(int kind, const double* albedo3, double param, const double* dir
     if (!scatter(m, ray, hit, rng, att, out)) return 0;
     out6[0] = att.x, out6[1] = att.y, out6[2] = att.z, out6[3] = out.dir.x, out6[4] = out.dir.y, out6[5] = out.dir.z;
     return 1;
+}
+// n samples of in_unit_sphere (which=0), unit(in_unit_sphere) (1) or in_unit_disk (2) with either sampler
+void ref_sample(int which, int sampler, uint64_t state, int n, double* out3n) {
+    Rng r{state};
+    for (int i = 0; i < n; ++i) {
+        Vec3 v = which == 0 ? gen_in_unit_sphere(r, sampler)
+                 : which == 1 ? (sampler == 1 ? direct_unit_vector(r) : unit(gen_in_unit_sphere(r)))
+                              : gen_in_unit_disk(r, sampler);
+        out3n[3 * i] = v.x, out3n[3 * i + 1] = v.y, out3n[3 * i + 2] = v.z;
+    }
 }
 double ref_reflectance(double cosine, double ri) { return reflectance(cosine, ri); }
 // first n uniforms of the stream for (seed, pixel, stratum)

@@ -12,12 +12,13 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # override: A/B of kernel builds
 
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 RT_SURF_SPHERE, RT_SURF_TRIANGLE, RT_SURF_QUAD = 0, 1, 2
 RT_KERNEL_PERSISTENT, RT_KERNEL_WAVEFRONT = 0, 1
 RT_DEVICE_CURRENT, RT_DEVICE_NONE = -1, -2
+RT_SAMPLER_REFERENCE, RT_SAMPLER_DIRECT = 0, 1
 
 # every symbol include/rt.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
@@ -75,7 +76,7 @@ class RtSceneInfo(C.Structure):
 class RtRenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("sn", C.c_uint32), ("max_depth", C.c_uint32),
                 ("seed", C.c_uint64), ("stratum_begin", C.c_uint32), ("stratum_step", C.c_uint32),
-                ("kernel", C.c_int32), ("collect_stats", C.c_int32)]
+                ("kernel", C.c_int32), ("collect_stats", C.c_int32), ("sampler", C.c_int32), ("_pad", C.c_int32)]
 
 
 class RtStats(C.Structure):
@@ -262,14 +263,15 @@ class Scene:
         return out
 
     @staticmethod
-    def _params(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel, collect_stats):
+    def _params(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel, collect_stats, sampler):
         return RtRenderParams(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel,
-                              1 if collect_stats else 0)
+                              1 if collect_stats else 0, sampler, 0)
 
     def render(self, width, height, sn, *, max_depth=40, seed=1, stratum_begin=0, stratum_step=1,
-               kernel=RT_KERNEL_PERSISTENT, collect_stats=False):
+               kernel=RT_KERNEL_PERSISTENT, collect_stats=False, sampler=RT_SAMPLER_DIRECT):
         """Pixel loop main.rs:150-185 for strata begin, begin+step, ...: returns (rgb_sum[H,W,3] f32, Stats)."""
-        p = self._params(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel, collect_stats)
+        p = self._params(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel, collect_stats,
+                         sampler)
         out = np.empty((height, width, 3), dtype=np.float32)
         st = RtStats()
         _check(lib().rt_render(self._h, C.byref(p), out.ctypes.data, C.byref(st)))
@@ -277,9 +279,10 @@ class Scene:
 
     def render_device(self, d_ptr: int, width, height, sn, *, max_depth=40, seed=1, stratum_begin=0,
                       stratum_step=1, kernel=RT_KERNEL_PERSISTENT, collect_stats=False, stream: int = 0,
-                      want_stats=True):
+                      want_stats=True, sampler=RT_SAMPLER_DIRECT):
         """Same, into device memory at ``d_ptr`` (e.g. a torch tensor's data_ptr()) on HIP stream ``stream``."""
-        p = self._params(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel, collect_stats)
+        p = self._params(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel, collect_stats,
+                         sampler)
         st = RtStats()
         _check(lib().rt_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream),
                                       C.byref(st) if want_stats else None))

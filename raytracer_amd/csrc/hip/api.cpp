@@ -408,6 +408,8 @@ DevRenderParams make_params(const rt_scene& s, const rt_render_params& p) {
     rp.stratum_step = p.stratum_step ? p.stratum_step : 1;
     rp.seed_lo = (uint32_t)p.seed, rp.seed_hi = (uint32_t)(p.seed >> 32);
     rp.recip_sn = (float)(1.0 / (double)p.sn);
+    if (p.sampler != RT_SAMPLER_REFERENCE && p.sampler != RT_SAMPLER_DIRECT) throw std::runtime_error("unknown sampler");
+    rp.sampler = (uint32_t)p.sampler;
     return rp;
 }
 

@@ -68,14 +68,48 @@ __device__ __forceinline__ D3 cross(D3 a, D3 b) {
 }
 __device__ __forceinline__ F3 tof(D3 v) { return {(float)v.x, (float)v.y, (float)v.z}; }
 
-// util.rs:15-24 / 26-35 — rejection sampling, same draw order as the reference.
-__device__ __forceinline__ F3 rng_in_unit_sphere(Rng& r) {
+// util.rs:15-24 / 26-35.  Two samplers with the same distributions:
+//   DIRECT == false  the reference's rejection loops, same draw order (parity mode: the oracle's default);
+//   DIRECT == true   closed-form maps with a fixed number of draws (2 for a direction or a disk point, 3 for
+//                    a ball point): no data-dependent loop, so no lane waits for the unluckiest lane of the
+//                    wave.  oracle/rt_ref.cpp restates both; v_sin/v_cos take their argument in turns.
+template <bool DIRECT>
+__device__ __forceinline__ F3 rng_unit_vector(Rng& r) {  // uniform on the unit sphere: unit(in_unit_sphere)
+    if (DIRECT) {
+        const float z = 1.0f - 2.0f * rng_u01(r);
+        const float turn = rng_u01(r);
+        const float rad = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        return {rad * __builtin_amdgcn_cosf(turn), rad * __builtin_amdgcn_sinf(turn), z};
+    }
+    while (true) {
+        float x = rng_pm1(r), y = rng_pm1(r), z = rng_pm1(r);
+        const float l2 = x * x + y * y + z * z;
+        if (l2 < 1.0f) {
+            const float inv_len = 1.0f / sqrtf(l2);
+            return {inv_len * x, inv_len * y, inv_len * z};
+        }
+    }
+}
+template <bool DIRECT>
+__device__ __forceinline__ F3 rng_in_unit_sphere(Rng& r) {  // uniform in the unit ball
+    if (DIRECT) {
+        const F3 u = rng_unit_vector<true>(r);
+        const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(rng_u01(r)) * (1.0f / 3.0f));  // cbrt
+        return rad * u;
+    }
     while (true) {
         float x = rng_pm1(r), y = rng_pm1(r), z = rng_pm1(r);
         if (x * x + y * y + z * z < 1.0f) return {x, y, z};
     }
 }
+template <bool DIRECT>
 __device__ __forceinline__ void rng_in_unit_disk(Rng& r, float& x, float& y) {
+    if (DIRECT) {
+        const float rad = sqrtf(rng_u01(r));
+        const float turn = rng_u01(r);
+        x = rad * __builtin_amdgcn_cosf(turn), y = rad * __builtin_amdgcn_sinf(turn);
+        return;
+    }
     while (true) {
         x = rng_pm1(r), y = rng_pm1(r);
         if (x * x + y * y < 1.0f) return;
@@ -109,6 +143,7 @@ struct TraceStats {
 };
 
 // Camera ray for (pixel, stratum): main.rs:157-174 + camera.rs:76-87.
+template <bool DIRECT>
 __device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
                                           uint32_t stratum, Rng& rng) {
     uint32_t si = stratum / rp.sn, sj = stratum - si * rp.sn;
@@ -117,7 +152,7 @@ __device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderPar
     float s = (float)(pi + 1) + ju;  // in pixel units; *hor_px == (centeru + jitteru*pixel_du)*horizontal
     float t = (float)(pj + 1) + jv;
     float rx, ry;
-    rng_in_unit_disk(rng, rx, ry);  // always drawn, even for a pinhole (camera.rs:77)
+    rng_in_unit_disk<DIRECT>(rng, rx, ry);  // always drawn, even for a pinhole (camera.rs:77)
     rx *= sc.cam.lens_radius, ry *= sc.cam.lens_radius;
     (void)rng_u01(rng);  // shutter time: drawn (camera.rs:80), without effect on stationary scenes
     F3 off = rx * f3(sc.cam.u) + ry * f3(sc.cam.v);
@@ -128,6 +163,20 @@ __device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderPar
 }
 
 // ---------------------------------------------------------------- primitive tests
+// f64 reciprocal / square root from the f32 hardware approximation plus one Newton step in f64: relative
+// error ~1e-14, a third of the instructions of the IEEE-exact expansions.  (The exact-parity kernel in
+// primary64.hip uses the IEEE operations; these are for the render path, whose arguments are well inside
+// the f32 exponent range.)
+__device__ __forceinline__ double rcp64(double b) {
+    const double r = (double)__builtin_amdgcn_rcpf((float)b);
+    return fma(fma(-b, r, 1.0), r, r);
+}
+__device__ __forceinline__ double sqrt64(double x) {  // x > 0
+    const double y = (double)__builtin_amdgcn_rsqf((float)x);  // ~ 1/sqrt(x)
+    const double s = x * y;                                    // ~ sqrt(x)
+    return fma(fma(-s, s, x), 0.5 * y, s);
+}
+
 // Sphere, f64 (surfaces.rs:73-106).  Returns the first root inside [tmin, tmax], or -1.
 __device__ __forceinline__ double sphere_root(const double* sp, D3 o, D3 d, double tmin, double tmax) {
     D3 oc = o - d3(sp);
@@ -137,10 +186,11 @@ __device__ __forceinline__ double sphere_root(const double* sp, D3 o, D3 d, doub
     double c = dot(oc, oc) - r * r;
     double disc = half_b * half_b - a * c;
     if (disc > 0.0) {
-        double root = sqrt(disc);
-        double t0 = (-half_b - root) / a;
+        double root = sqrt64(disc);
+        double ia = rcp64(a);
+        double t0 = (-half_b - root) * ia;
         if (tmin <= t0 && t0 <= tmax) return t0;
-        double t1 = (-half_b + root) / a;
+        double t1 = (-half_b + root) * ia;
         if (tmin <= t1 && t1 <= tmax) return t1;
     }
     return -1.0;
@@ -151,7 +201,7 @@ __device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double 
     D3 n = d3(q);
     double denom = dot(n, d);
     if (fabs(denom) < 1e-8) return -1.0;
-    double t = (q[3] - dot(n, o)) / denom;
+    double t = (q[3] - dot(n, o)) * rcp64(denom);
     if (t < 1e-4 || !(tmin <= t && t <= tmax)) return -1.0;
     D3 p = (o + t * d) - d3(q + 4);
     double alpha = dot(p, d3(q + 7));
@@ -352,6 +402,7 @@ __device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (2.0f * dot(v, n)
 // One bounce (one iteration of the loop at scene/mod.rs:103-125).  `lsum` gathers radiance in the forward
 // form  L += T*emitted; T *= albedo  (equal to resolve_color's back-to-front fold).  Returns whether the
 // path continues; `depth` follows the reference's counter including the metal re-sampling quirk (Q1).
+template <bool DIRECT>
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const HitRec& hit, float tmin, Rng& rng,
                                              F3& thr, F3& lsum, uint32_t& depth, uint32_t max_depth) {
     if (hit.slot == -1) {  // escaped: (0, background), scene/mod.rs:122
@@ -403,14 +454,12 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
     }
     F3 dir;
     if (kind == 0) {  // Lambertian, material.rs:100-118
-        const F3 s = rng_in_unit_sphere(rng);
-        const float inv_len = 1.0f / sqrtf(dot(s, s));
-        dir = n + inv_len * s;
+        dir = n + rng_unit_vector<DIRECT>(rng);
         if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
     } else if (kind == 1) {  // Metal, material.rs:126-138 + the re-sampling loop of Q1
         const F3 refl = reflect(ray.d, n);  // incoming direction not normalised (Q2)
         while (true) {
-            const F3 s = rng_in_unit_sphere(rng);
+            const F3 s = rng_in_unit_sphere<DIRECT>(rng);
             dir = refl + m.w * s;
             if (dot(dir, n) > 1e-8f) break;
             // absorbed: nothing pushed, depth += 1, same ray re-traced to the same hit, fuzz re-drawn

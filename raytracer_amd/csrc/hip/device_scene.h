@@ -64,6 +64,7 @@ struct DevRenderParams {
     uint32_t stratum_begin, stratum_step, n_strata;  // n_strata = sn*sn
     uint32_t seed_lo, seed_hi;
     float recip_sn;
+    uint32_t sampler;  // RT_SAMPLER_*
 };
 
 struct DevCounters {  // one instance in HBM, bumped with one atomic per wave at kernel end

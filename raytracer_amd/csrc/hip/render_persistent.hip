@@ -18,6 +18,9 @@
 namespace rt {
 
 constexpr int kBlock = 256;
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4
+#endif
 constexpr uint32_t kChunkStrata = 16;  // strata per chunk (a chunk is 64 pixels x this many strata)
 
 struct PersistentPlan {
@@ -34,8 +37,8 @@ struct PersistentPlan {
 constexpr int kStageShade = kTraversalDone;
 constexpr int kStageIdle = 0x7ffffffe;
 
-template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+template <int STACK, bool STATS, bool DIRECT>
+__global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ rgb_sum,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
             const bool mine = node == kStageShade;
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
-                alive = shade_bounce(sc, ray, best.h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+                alive = shade_bounce<DIRECT>(sc, ray, best.h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     atomicAdd(&rgb_sum[3 * pix + 0], lsum.x);
                     atomicAdd(&rgb_sum[3 * pix + 1], lsum.y);
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
                             rp.stratum_begin + (chunk_group * kChunkStrata + (j >> 6)) * rp.stratum_step;
                         pix = py * rp.width + px;  // == the reference's idx: pi = idx % W, pj = H - idx/W - 1
                         rng_init(rng, seed, pix, stratum);
-                        ray = camera_ray(sc, rp, px, rp.height - py - 1u, stratum, rng);
+                        ray = camera_ray<DIRECT>(sc, rp, px, rp.height - py - 1u, stratum, rng);
                         thr = {1.f, 1.f, 1.f};
                         lsum = {0.f, 0.f, 0.f};
                         depth = 0;
@@ -174,16 +177,22 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(DevScene sc, 
     }
 }
 
+template <int STACK, bool STATS, bool DIRECT>
+static void launch_one(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
+                       float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter, hipStream_t stream) {
+    hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp,
+                       plan, d_rgb_sum, counters, work_counter);
+}
+
 template <int STACK>
 static hipError_t launch_stack(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
                                float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter, bool stats,
                                hipStream_t stream) {
-    if (stats)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, true>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp, plan,
-                           d_rgb_sum, counters, work_counter);
-    else
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, false>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp, plan,
-                           d_rgb_sum, counters, work_counter);
+    const bool direct = rp.sampler != 0;
+    if (stats && direct) launch_one<STACK, true, true>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
+    if (stats && !direct) launch_one<STACK, true, false>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
+    if (!stats && direct) launch_one<STACK, false, true>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
+    if (!stats && !direct) launch_one<STACK, false, false>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
     return hipGetLastError();
 }
 

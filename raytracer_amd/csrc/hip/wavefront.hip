@@ -41,6 +41,7 @@ __device__ __forceinline__ Ray load_ray(const WavefrontBuffers& b, uint32_t p) {
 }
 
 // camera.rs:76-87 + main.rs:157-174 for every (pixel, stratum) of the batch; path p -> pixel p % n_pixels.
+template <bool DIRECT>
 __global__ __launch_bounds__(kWBlock) void wf_raygen(DevScene sc, DevRenderParams rp, WavefrontBuffers b, Batch bt) {
     const uint64_t seed = ((uint64_t)rp.seed_hi << 32) | rp.seed_lo;
     if (blockIdx.x == 0 && threadIdx.x == 0) b.counts[0] = bt.n_paths;  // level-0 queue = every path of the batch
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(kWBlock) void wf_raygen(DevScene sc, DevRenderParam
         const uint32_t pi = idx % rp.width, pj = rp.height - idx / rp.width - 1u;
         Rng rng;
         rng_init(rng, seed, idx, stratum);
-        const Ray ray = camera_ray(sc, rp, pi, pj, stratum, rng);
+        const Ray ray = camera_ray<DIRECT>(sc, rp, pi, pj, stratum, rng);
         store_ray(b, p, ray);
         const uint32_t c = b.capacity;
         b.thr[p] = 1.f, b.thr[c + p] = 1.f, b.thr[2 * c + p] = 1.f;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(kWBlock) void wf_extend(DevScene sc, WavefrontBuffe
 // shade: emit + scatter (material.rs:59-181, scene/mod.rs:105-123); a path that ends adds its radiance to the
 // framebuffer (every path contributes exactly once: at a light, at the sky, or zero); survivors are appended
 // to the next level's queue.
+template <bool DIRECT>
 __global__ __launch_bounds__(kWBlock) void wf_shade(DevScene sc, DevRenderParams rp, WavefrontBuffers b,
                                                     const uint32_t* __restrict__ queue_in,
                                                     uint32_t* __restrict__ queue_out, uint32_t* __restrict__ counts,
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(kWBlock) void wf_shade(DevScene sc, DevRenderParams
             F3 thr = {b.thr[p], b.thr[c + p], b.thr[2 * c + p]};
             F3 lsum = {0.f, 0.f, 0.f};
             uint32_t depth = b.depth[p];
-            alive = shade_bounce(sc, ray, h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+            alive = shade_bounce<DIRECT>(sc, ray, h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
             if (alive) {
                 store_ray(b, p, ray);
                 b.thr[p] = thr.x, b.thr[c + p] = thr.y, b.thr[2 * c + p] = thr.z;
@@ -214,7 +216,10 @@ hipError_t render_wavefront(WavefrontState& st, const DevScene& sc, const DevRen
         bt.n_paths = std::min(strata_per_batch, my_strata - first) * n_pixels;
         const dim3 grid(std::min(fill_blocks, (bt.n_paths + kWBlock - 1) / kWBlock));
         if ((e = hipMemsetAsync(st.buf.counts, 0, ((size_t)kMaxLevels + 1) * sizeof(uint32_t), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(wf_raygen, grid, dim3(kWBlock), 0, stream, sc, rp, st.buf, bt);
+        if (rp.sampler != 0)
+            hipLaunchKernelGGL(wf_raygen<true>, grid, dim3(kWBlock), 0, stream, sc, rp, st.buf, bt);
+        else
+            hipLaunchKernelGGL(wf_raygen<false>, grid, dim3(kWBlock), 0, stream, sc, rp, st.buf, bt);
         ++launches;
         // The metal re-sampling quirk can add more than one to `depth` per bounce, so a path dies after at most
         // max_depth levels; queues beyond the last live level are empty and their kernels fall straight through.
@@ -227,8 +232,12 @@ hipError_t render_wavefront(WavefrontState& st, const DevScene& sc, const DevRen
                 launch_extend<40>(stats, grid, stream, sc, st.buf, qin, level, counters);
             else
                 launch_extend<64>(stats, grid, stream, sc, st.buf, qin, level, counters);
-            hipLaunchKernelGGL(wf_shade, grid, dim3(kWBlock), 0, stream, sc, rp, st.buf, qin, qout, st.buf.counts, level,
-                               d_rgb_sum);
+            if (rp.sampler != 0)
+                hipLaunchKernelGGL(wf_shade<true>, grid, dim3(kWBlock), 0, stream, sc, rp, st.buf, qin, qout, st.buf.counts,
+                                   level, d_rgb_sum);
+            else
+                hipLaunchKernelGGL(wf_shade<false>, grid, dim3(kWBlock), 0, stream, sc, rp, st.buf, qin, qout, st.buf.counts,
+                                   level, d_rgb_sum);
             launches += 2;
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;

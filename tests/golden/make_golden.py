@@ -31,11 +31,13 @@ def main():
         order, stats = o.leaf_order()
         iw, ih, sn = IMAGE
         o2 = ref.RefScene.from_yaml(path, iw / ih)
-        img, cnt = o2.render(iw, ih, sn, max_depth=40, seed=1)
+        img, cnt = o2.render(iw, ih, sn, max_depth=40, seed=1)                 # reference sampler (rejection)
+        img_d, cnt_d = o2.render(iw, ih, sn, max_depth=40, seed=1, sampler=1)  # direct sampler
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), prim_id=ids, t=t, leaf_order_head=order[:4096],
                             leaf_order_sum=np.int64(np.sum(order.astype(np.int64) * np.arange(1, len(order) + 1))),
                             tree=np.array([stats["nodes"], stats["leaves"], stats["depth"], stats["max_leaf"]]),
-                            image_sum=img, segments=np.int64(cnt["segments"]))
+                            image_sum=img, segments=np.int64(cnt["segments"]), image_sum_direct=img_d,
+                            segments_direct=np.int64(cnt_d["segments"]))
         print(name, "hits", int((ids >= 0).sum()), "tree", stats, "mean", float(img.mean()) / (sn * sn))
 
 

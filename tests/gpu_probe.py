@@ -20,7 +20,7 @@ def main():
             rel = float(np.max(np.abs(t[both] - rt[both]) / rt[both])) if both.any() else 0.0
             print(f"{name} f{prec}: id mismatches {mism}/{w*h}  max rel t err {rel:.3e}", flush=True)
         sn = 4
-        want, cnt = o.render(w, h, sn, threads=16)
+        want, cnt = o.render(w, h, sn, threads=16, sampler=1)
         want /= sn * sn
         for k, kn in ((0, "persistent"), (1, "wavefront")):
             img, st = s.render(w, h, sn, kernel=k, collect_stats=True)

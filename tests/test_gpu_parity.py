@@ -95,13 +95,18 @@ def _check_image(got_sum, want_sum, n, name):
     assert abs(got.mean() - want.mean()) <= IMG_LUM * max(want.mean(), 1e-6), (name, got.mean(), want.mean())
 
 
+@pytest.mark.parametrize("sampler", [0, 1])
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("name", SCENES)
-def test_image_matches_golden(ra, scenes, name, kernel):
+def test_image_matches_golden(ra, scenes, name, kernel, sampler):
+    """Same sampler on both sides (0: the reference's rejection loops, 1: the direct maps): GPU and oracle then
+    follow the same paths sample by sample."""
     g = golden(name)
-    ih, iw, _ = g["image_sum"].shape
-    img, st = scenes(name, iw / ih).render(iw, ih, 4, max_depth=40, seed=1, kernel=kernel, collect_stats=True)
-    _check_image(img, g["image_sum"], 16, name)
+    want = g["image_sum"] if sampler == 0 else g["image_sum_direct"]
+    ih, iw, _ = want.shape
+    img, st = scenes(name, iw / ih).render(iw, ih, 4, max_depth=40, seed=1, kernel=kernel, collect_stats=True,
+                                           sampler=sampler)
+    _check_image(img, want, 16, name)
     assert st.samples == iw * ih * 16
     # The GPU ends a path at a light / an absorbed metal bounce without re-tracing (Q1), so it traces no more
     # segments than the reference, up to the few paths whose f32 and f64 versions part ways (2 % allowed).
@@ -110,10 +115,12 @@ def test_image_matches_golden(ra, scenes, name, kernel):
 
 @pytest.mark.parametrize("name,w,h,sn", [("teapot", 160, 90, 6), ("cornell_lucy", 96, 96, 6), ("distant", 160, 90, 8)])
 def test_image_matches_oracle_higher_spp(scenes, ref, name, w, h, sn):
-    want, _ = ref.RefScene.from_yaml(scene_path(name), w / h).render(w, h, sn, threads=16)
-    for kernel in (0, 1):
-        img, _ = scenes(name, w / h).render(w, h, sn, kernel=kernel)
-        _check_image(img, want, sn * sn, name)
+    o = ref.RefScene.from_yaml(scene_path(name), w / h)
+    for sampler in (0, 1):
+        want, _ = o.render(w, h, sn, threads=16, sampler=sampler)
+        for kernel in (0, 1):
+            img, _ = scenes(name, w / h).render(w, h, sn, kernel=kernel, sampler=sampler)
+            _check_image(img, want, sn * sn, name)
 
 
 def _same_image(a, b, n):
@@ -176,8 +183,8 @@ def test_max_depth_and_metal_resampling_quirk(scenes, ref):
     name, w, h = "dual", 96, 54
     o = ref.RefScene.from_yaml(scene_path(name), w / h)
     for md in (1, 2, 5):
-        want, _ = o.render(w, h, 3, max_depth=md, threads=16)
-        got, _ = scenes(name, w / h).render(w, h, 3, max_depth=md)
+        want, _ = o.render(w, h, 3, max_depth=md, threads=16, sampler=0)
+        got, _ = scenes(name, w / h).render(w, h, 3, max_depth=md, sampler=0)
         _check_image(got, want, 9, f"{name} max_depth={md}")
 
 
@@ -197,3 +204,15 @@ def test_full_size_frame_properties(scenes):
     q = scenes("quads", 1920 / 1080)
     img, _ = q.render(1920, 1080, 3)
     assert np.allclose(img[0, 0] / 9, [0.7, 0.8, 1.0], rtol=1e-6)  # the top-left corner looks past every quad
+
+
+def test_direct_sampler_is_distribution_equal_on_the_gpu(scenes, ref):
+    """Cross check of the two samplers through the product path: GPU(direct) against oracle(REFERENCE sampler)
+    at high spp — different variates, so the bound is statistical (two independent 1024-spp estimates)."""
+    # cornell's small area light makes it the noisier of the two: independent 1024-spp estimates differ by ~0.03
+    for name, w, h, tol in (("teapot", 96, 54, 0.03), ("cornell", 64, 64, 0.06)):
+        want, _ = ref.RefScene.from_yaml(scene_path(name), w / h).render(w, h, 32, threads=16, sampler=0)
+        got, _ = scenes(name, w / h).render(w, h, 32, sampler=1)
+        a, b = got.astype(np.float64) / 1024, want / 1024
+        assert abs(a.mean() - b.mean()) <= 0.01 * b.mean()
+        assert np.sqrt(np.mean((a - b) ** 2)) <= tol
