@@ -18,6 +18,9 @@
 namespace rt {
 
 constexpr int kBlock = 256;
+#ifndef RT_NODE_STEPS
+#define RT_NODE_STEPS 3
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
@@ -82,7 +85,10 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         const bool run_shade = n_shade >= plan.shade_threshold || (n_node | n_leaf) == 0;
         if (!run_shade && n_node >= n_leaf) {
             if (STATS) trips[0]++, lanes_on[0] += n_node;
-            if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, kBlock, sp, st);
+            // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
+#pragma unroll 1
+            for (int k = 0; k < RT_NODE_STEPS; ++k)
+                if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, kBlock, sp, st);
         } else if (!run_shade) {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf;
             if (node < 0) {
