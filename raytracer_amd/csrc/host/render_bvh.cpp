@@ -3,6 +3,7 @@
 // as lucy.yaml; on a 64-lane machine short, uniform leaves matter more than build fidelity).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "bvh_build.h"
 
@@ -11,7 +12,7 @@ namespace rt {
 namespace {
 
 constexpr int kBins = 32;
-constexpr double kTraversalCost = 1.0;  // relative to one primitive test
+static double kTraversalCost = 1.0;  // relative to one primitive test
 constexpr double kIntersectCost = 1.0;
 
 struct Item {
@@ -112,6 +113,7 @@ struct RBuilder {
 
 void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out) {
     out = Bvh{};
+    if (getenv("RT_CT")) kTraversalCost = atof(getenv("RT_CT"));
     RBuilder b;
     b.out = &out;
     b.max_leaf = std::max(1u, max_leaf);
