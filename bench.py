@@ -71,13 +71,16 @@ def cpu_baseline(scene_file: str, width: int, height: int, sn: int, threads: int
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="lucy")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--kernel", choices=["persistent", "wavefront"], default="persistent")
+    ap.add_argument("--sampler", choices=["direct", "reference"], default="direct",
+                    help="unit-sphere/disk sampling: loop-free direct maps (default) or the reference's rejection loops; "
+                         "same distributions (tests/test_golden.py, tests/test_gpu_parity.py)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sn", type=int, default=6, help="strata per axis of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,6 +110,7 @@ def main() -> None:
     w, h = args.width, args.height
     sn = int(np.floor(np.sqrt(args.spp)))  # main.rs:142
     kernel = ra.RT_KERNEL_PERSISTENT if args.kernel == "persistent" else ra.RT_KERNEL_WAVEFRONT
+    sampler = ra.RT_SAMPLER_DIRECT if args.sampler == "direct" else ra.RT_SAMPLER_REFERENCE
     t0 = time.perf_counter()
     desc = ra.load_scene(scene_file, w / h)
     scene = ra.Scene(desc, local_rank)
@@ -121,7 +125,7 @@ def main() -> None:
 
     def one_step():
         st = scene.render_device(fb.data_ptr(), w, h, sn, max_depth=40, seed=args.seed, stratum_begin=begin,
-                                 stratum_step=step_, kernel=kernel, stream=stream)
+                                 stratum_step=step_, kernel=kernel, stream=stream, sampler=sampler)
         kernel_ms.append(st.kernel_ms)  # HIP events on `stream`, around this step's render kernels
         reduce_framebuffer(fb, world)
         if rank == 0:
@@ -155,15 +159,17 @@ def main() -> None:
     # Algorithmic work per sample from the counting build of the same kernel, outside the timed region,
     # at reduced spp (per-sample counts do not depend on spp).
     cnt = scene.render_device(fb.data_ptr(), w, h, min(sn, 4), max_depth=40, seed=args.seed, kernel=kernel,
-                              collect_stats=True, stream=stream)
+                              collect_stats=True, stream=stream, sampler=sampler)
     fl = flops_per_sample(cnt)
     my_samples = last.samples  # samples this rank rendered per step
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved_tflops = fl * my_samples / avg_kernel_s / 1e12
-    # HBM traffic that the algorithm needs per launch: the framebuffer write (12 B/pixel); the wavefront form
-    # adds its path-state queues (~216 B per segment).
+    # HBM-side traffic the algorithm needs per launch: one 12-byte float-atomic add per finished sample plus the
+    # 12 B/pixel clear (persistent kernel); the wavefront form adds its path-state queues (~216 B per segment).
     seg_per_sample = cnt.segments / max(cnt.samples, 1)
-    hbm_bytes = 12.0 * w * h + (216.0 * seg_per_sample * my_samples if kernel == ra.RT_KERNEL_WAVEFRONT else 0.0)
+    hbm_bytes = 12.0 * w * h + 12.0 * my_samples
+    if kernel == ra.RT_KERNEL_WAVEFRONT:
+        hbm_bytes += 216.0 * seg_per_sample * my_samples
 
     if rank == 0:
         line = {
@@ -172,9 +178,10 @@ def main() -> None:
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scenes/{args.scene}.yaml {w}x{h} {sn * sn} spp, max_depth 40, "
-                                   f"{args.kernel} kernel", "seconds_per_frame": round(elapsed / args.steps, 4),
+                                   f"{args.kernel} kernel, {args.sampler} sampler", "seconds_per_frame": round(elapsed / args.steps, 4),
                        "parallelism": f"strata-sharded x{world}, 1 RCCL sum-reduce/frame" if world > 1 else "1 GPU",
-                       "scene_surfaces": int(info.n_surfaces), "bvh_nodes": int(info.n_nodes),
+                       "scene_surfaces": int(info.n_surfaces), "render_bvh_nodes": int(info.render_nodes),
+                       "render_bvh_depth": int(info.render_depth), "loose_prims": int(info.n_loose),
                        "scene_setup_s": round(setup_s, 3)},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved_tflops, 4), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),

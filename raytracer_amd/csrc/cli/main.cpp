@@ -1,6 +1,6 @@
 // `raytracer` — command line of the reference (clap derive, main.rs:23-66) over the C ABI in include/rt.h.
 // Same flag names, defaults and conflict rule; same stderr "Done in …" line (main.rs:190) and RGB8 PNG
-// (main.rs:192-200).  Extra flags: --gpus N, --kernel persistent|wavefront, --dump-primary FILE, --json.
+// (main.rs:192-200).  Extra flags: --gpus N, --kernel persistent|wavefront, --sampler direct|reference, --dump-primary FILE, --json.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -27,6 +27,7 @@ struct Opt {
     bool no_progress = false, no_bvh = false, json = false;
     int gpus = 1;
     int kernel = RT_KERNEL_PERSISTENT;
+    int sampler = RT_SAMPLER_DIRECT;
 };
 
 [[noreturn]] void usage_error(const std::string& m) {
@@ -51,6 +52,7 @@ void help() {
         "      --no-bvh                       Disables the use of the bvh acceleration structure\n"
         "      --gpus <N>                     Shard the strata over N GPUs [default: 1]\n"
         "      --kernel <persistent|wavefront>\n"
+        "      --sampler <direct|reference>   Unit-sphere/disk sampling: loop-free maps or the reference's rejection loops\n"
         "      --dump-primary <FILE>          Write the f64 primary-hit AOV (int32 ids, then f64 t) and exit\n"
         "      --json                         Print a JSON metrics line on stdout\n"
         "  -h, --help                         Print help");
@@ -102,6 +104,11 @@ Opt parse(int argc, char** argv) {
             if (v == "persistent") o.kernel = RT_KERNEL_PERSISTENT;
             else if (v == "wavefront") o.kernel = RT_KERNEL_WAVEFRONT;
             else usage_error("invalid value '" + v + "' for '--kernel'");
+        } else if (key == "--sampler") {
+            std::string v = need(i, "--sampler");
+            if (v == "direct") o.sampler = RT_SAMPLER_DIRECT;
+            else if (v == "reference") o.sampler = RT_SAMPLER_REFERENCE;
+            else usage_error("invalid value '" + v + "' for '--sampler'");
         } else usage_error("unexpected argument '" + a + "' found");
     }
     if (o.has_height && o.has_aspect)  // #[arg(long, conflicts_with = "height")], main.rs:44
@@ -172,7 +179,7 @@ int main(int argc, char** argv) {
         pool.emplace_back([&, g]() {
             rt_render_params p{};
             p.width = (uint32_t)width, p.height = (uint32_t)height, p.sn = sn, p.max_depth = max_depth;
-            p.seed = seed, p.stratum_begin = (uint32_t)g, p.stratum_step = (uint32_t)o.gpus, p.kernel = o.kernel;
+            p.seed = seed, p.stratum_begin = (uint32_t)g, p.stratum_step = (uint32_t)o.gpus, p.kernel = o.kernel, p.sampler = o.sampler;
             rc[(size_t)g] = rt_render(scenes[(size_t)g], &p, parts[(size_t)g].data(), &stats[(size_t)g]);
             if (rc[(size_t)g]) errs[(size_t)g] = rt_last_error();
         });
