@@ -81,6 +81,8 @@ struct rt_scene {
     DevScene dev{};
     std::vector<void*> allocations;
     DevCounters* d_counters = nullptr;
+    float* d_acc = nullptr;  // persistent kernel's tile-planar accumulator (scratch)
+    size_t acc_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unique_ptr<WavefrontState> wf;
 
@@ -98,6 +100,7 @@ struct rt_scene {
             if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess) {
                 wf.reset();
                 for (void* p : allocations) (void)hipFree(p);
+                if (d_acc) (void)hipFree(d_acc);
                 if (ev0) (void)hipEventDestroy(ev0);
                 if (ev1) (void)hipEventDestroy(ev1);
                 (void)hipSetDevice(prev);
@@ -527,8 +530,19 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
         if (stats) HIP_CHECK(hipEventRecord(scene->ev0, stream));
         uint32_t n_launches = 1;
         if (params->kernel == RT_KERNEL_PERSISTENT) {
-            HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, d_rgb_sum, scene->d_counters,
-                                               &scene->d_counters->work, count, stream));
+            // scratch: the tile-planar accumulator, kept with the scene and grown on demand
+            const size_t need = persistent_acc_bytes(rp.width, rp.height);
+            if (scene->acc_bytes < need) {
+                if (scene->d_acc) {
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    HIP_CHECK(hipFree(scene->d_acc));
+                    scene->d_acc = nullptr, scene->acc_bytes = 0;
+                }
+                HIP_CHECK(hipMalloc((void**)&scene->d_acc, need));
+                scene->acc_bytes = need;
+            }
+            HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, scene->d_acc, d_rgb_sum,
+                                               scene->d_counters, &scene->d_counters->work, count, stream));
         } else if (params->kernel == RT_KERNEL_WAVEFRONT) {
             if (!scene->wf) scene->wf = std::make_unique<WavefrontState>();
             HIP_CHECK(render_wavefront(*scene->wf, dev, rp, scene->stack_depth, d_rgb_sum, scene->d_counters, count,

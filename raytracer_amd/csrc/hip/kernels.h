@@ -7,8 +7,10 @@
 namespace rt {
 
 hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& rp, uint32_t tree_depth,
-                                    uint32_t n_cus, float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter,
-                                    bool stats, hipStream_t stream);
+                                    uint32_t n_cus, float* d_acc, float* d_rgb_sum, DevCounters* counters,
+                                    uint32_t* work_counter, bool stats, hipStream_t stream);
+// bytes of the tile-planar accumulator the persistent kernel adds into (d_acc above)
+size_t persistent_acc_bytes(uint32_t width, uint32_t height);
 hipError_t launch_tonemap(const float* d_rgb_sum, uint32_t n_values, double n_samples, uint8_t* d_out,
                           hipStream_t stream);
 hipError_t launch_primary64(const DevScene& sc, uint32_t width, uint32_t height, int32_t* d_prim_id, double* d_t,

@@ -42,7 +42,7 @@ constexpr int kStageIdle = 0x7ffffffe;
 
 template <int STACK, bool STATS, bool DIRECT>
 __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
-                                                                   float* __restrict__ rgb_sum,
+                                                                   float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
     __shared__ int lds_stack[STACK * kBlock];
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     closest_reset(best);
     Rng rng;
     rng.s = 0;
-    uint32_t depth = 0, pix = 0;
+    uint32_t depth = 0, pix = 0;  // pix = tile * 64 + position in tile
     bool alive = false;   // a path is in flight
     int node = kStageShade;
     int sp = 0;
@@ -103,9 +103,11 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             if (mine && alive) {
                 alive = shade_bounce<DIRECT>(sc, ray, best.h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
-                    atomicAdd(&rgb_sum[3 * pix + 0], lsum.x);
-                    atomicAdd(&rgb_sum[3 * pix + 1], lsum.y);
-                    atomicAdd(&rgb_sum[3 * pix + 2], lsum.z);
+                    // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
+                    float* a = acc + (size_t)(pix >> 6) * 192u + (pix & 63u);
+                    atomicAdd(a, lsum.x);
+                    atomicAdd(a + 64, lsum.y);
+                    atomicAdd(a + 128, lsum.z);
                 }
             }
             // ---- regenerate: lanes without a path take the next samples of the chunk (uniform control flow)
@@ -137,8 +139,9 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                     if (px < rp.width && py < rp.height) {
                         const uint32_t stratum =
                             rp.stratum_begin + (chunk_group * kChunkStrata + (j >> 6)) * rp.stratum_step;
-                        pix = py * rp.width + px;  // == the reference's idx: pi = idx % W, pj = H - idx/W - 1
-                        rng_init(rng, seed, pix, stratum);
+                        pix = chunk_tile * 64u + in_tile;  // slot in the tile-planar accumulator
+                        // the stream key is the reference's idx: pi = idx % W, pj = H - idx/W - 1
+                        rng_init(rng, seed, py * rp.width + px, stratum);
                         ray = camera_ray<DIRECT>(sc, rp, px, rp.height - py - 1u, stratum, rng);
                         thr = {1.f, 1.f, 1.f};
                         lsum = {0.f, 0.f, 0.f};
@@ -183,11 +186,23 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     }
 }
 
+// tile-planar accumulator -> the caller's row-major interleaved framebuffer (row 0 = top, main.rs:158)
+__global__ void resolve_kernel(const float* __restrict__ acc, uint32_t width, uint32_t height, uint32_t tiles_x,
+                               float* __restrict__ rgb_sum) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t px = i % width, py = i / width;
+    const float* a = acc + (size_t)((py >> 3) * tiles_x + (px >> 3)) * 192u + ((py & 7u) * 8u + (px & 7u));
+    rgb_sum[3 * i + 0] = a[0];
+    rgb_sum[3 * i + 1] = a[64];
+    rgb_sum[3 * i + 2] = a[128];
+}
+
 template <int STACK, bool STATS, bool DIRECT>
 static void launch_one(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
-                       float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter, hipStream_t stream) {
+                       float* d_acc, DevCounters* counters, uint32_t* work_counter, hipStream_t stream) {
     hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp,
-                       plan, d_rgb_sum, counters, work_counter);
+                       plan, d_acc, counters, work_counter);
 }
 
 template <int STACK>
@@ -203,8 +218,8 @@ static hipError_t launch_stack(const DevScene& sc, const DevRenderParams& rp, co
 }
 
 hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& rp, uint32_t tree_depth,
-                                    uint32_t n_cus, float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter,
-                                    bool stats, hipStream_t stream) {
+                                    uint32_t n_cus, float* d_acc, float* d_rgb_sum, DevCounters* counters,
+                                    uint32_t* work_counter, bool stats, hipStream_t stream) {
     PersistentPlan plan;
     plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T")) : 40;
     plan.tiles_x = (rp.width + 7u) >> 3;
@@ -215,18 +230,31 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     if ((uint64_t)plan.n_tiles * plan.groups >= (1ull << 32)) return hipErrorInvalidValue;
     plan.n_chunks = plan.n_tiles * plan.groups;
 
-    hipError_t e = hipMemsetAsync(d_rgb_sum, 0, (size_t)3 * rp.width * rp.height * sizeof(float), stream);
+    hipError_t e = hipMemsetAsync(d_acc, 0, persistent_acc_bytes(rp.width, rp.height), stream);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-    if (plan.n_chunks == 0) return hipSuccess;
+    const uint32_t n_pixels = rp.width * rp.height;
+    if (plan.n_chunks == 0) {
+        hipLaunchKernelGGL(resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, d_acc, rp.width, rp.height,
+                           plan.tiles_x, d_rgb_sum);
+        return hipGetLastError();
+    }
     // Enough blocks to fill every CU at the occupancy the kernel's registers and LDS allow; surplus blocks are
     // harmless (they start when a slot frees up and find the counter exhausted).
     const uint32_t blocks = std::min<uint32_t>(n_cus * 8u, (plan.n_chunks + 3u) / 4u);
     // near-first traversal keeps at most (depth - 1) deferred children
-    if (tree_depth <= 24) return launch_stack<24>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stats, stream);
-    if (tree_depth <= 40) return launch_stack<40>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stats, stream);
-    if (tree_depth <= 64) return launch_stack<64>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stats, stream);
-    return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
+    if (tree_depth <= 24) e = launch_stack<24>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
+    else if (tree_depth <= 40) e = launch_stack<40>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
+    else if (tree_depth <= 64) e = launch_stack<64>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
+    else return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, d_acc, rp.width, rp.height,
+                       plan.tiles_x, d_rgb_sum);
+    return hipGetLastError();
+}
+
+size_t persistent_acc_bytes(uint32_t width, uint32_t height) {
+    return (size_t)((width + 7u) >> 3) * ((height + 7u) >> 3) * 192u * sizeof(float);
 }
 
 // main.rs:177-180, 209-221 (average in f64 like the reference's Vec3 / f64)
