@@ -135,7 +135,12 @@ int rt_scene_leaf_order(const rt_scene* scene, int32_t* out_surface_ids);
 
 /* ---- the hot path: replaces the pixel loop main.rs:150-185 ---- */
 
-enum { RT_KERNEL_PERSISTENT = 0, RT_KERNEL_WAVEFRONT = 1 };
+/* Three organisations of the same loop (same samples, same arithmetic):
+ *   PERSISTENT: one path per lane, stage-scheduled waves;
+ *   WAVEFRONT:  one kernel per stage, path state in HBM queues;
+ *   POOL:       stage-scheduled waves that own more paths than lanes (LDS pool); falls back to PERSISTENT
+ *               where it does not apply (no tree in the scene, max_depth > 63, frames beyond 2^26 pixels). */
+enum { RT_KERNEL_PERSISTENT = 0, RT_KERNEL_WAVEFRONT = 1, RT_KERNEL_POOL = 2 };
 /* How unit-sphere / unit-disk samples are drawn (util.rs:15-35).  Same distributions:
  *   REFERENCE: the reference's rejection loops, in its draw order;
  *   DIRECT:    closed-form maps with a fixed number of draws (no data-dependent loop on the GPU). */

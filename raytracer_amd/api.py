@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  
 
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 RT_SURF_SPHERE, RT_SURF_TRIANGLE, RT_SURF_QUAD = 0, 1, 2
-RT_KERNEL_PERSISTENT, RT_KERNEL_WAVEFRONT = 0, 1
+RT_KERNEL_PERSISTENT, RT_KERNEL_WAVEFRONT, RT_KERNEL_POOL = 0, 1, 2
 RT_DEVICE_CURRENT, RT_DEVICE_NONE = -1, -2
 RT_SAMPLER_REFERENCE, RT_SAMPLER_DIRECT = 0, 1
 

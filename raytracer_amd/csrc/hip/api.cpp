@@ -529,7 +529,7 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
         if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, sizeof(DevCounters), stream));
         if (stats) HIP_CHECK(hipEventRecord(scene->ev0, stream));
         uint32_t n_launches = 1;
-        if (params->kernel == RT_KERNEL_PERSISTENT) {
+        if (params->kernel == RT_KERNEL_PERSISTENT || params->kernel == RT_KERNEL_POOL) {
             // scratch: the tile-planar accumulator, kept with the scene and grown on demand
             const size_t need = persistent_acc_bytes(rp.width, rp.height);
             if (scene->acc_bytes < need) {
@@ -541,8 +541,12 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                 HIP_CHECK(hipMalloc((void**)&scene->d_acc, need));
                 scene->acc_bytes = need;
             }
-            HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, scene->d_acc, d_rgb_sum,
-                                               scene->d_counters, &scene->d_counters->work, count, stream));
+            // the pooled kernel only pays when rays traverse a tree; it packs depth and pixel into one word
+            const bool pooled = params->kernel == RT_KERNEL_POOL && dev.has_tree && rp.max_depth <= 63u &&
+                                pool_kernel_supports(rp.width, rp.height, scene->stack_depth);
+            HIP_CHECK((pooled ? launch_render_pool : launch_render_persistent)(
+                dev, rp, scene->stack_depth, scene->n_cus, scene->d_acc, d_rgb_sum, scene->d_counters,
+                &scene->d_counters->work, count, stream));
         } else if (params->kernel == RT_KERNEL_WAVEFRONT) {
             if (!scene->wf) scene->wf = std::make_unique<WavefrontState>();
             HIP_CHECK(render_wavefront(*scene->wf, dev, rp, scene->stack_depth, d_rgb_sum, scene->d_counters, count,
@@ -567,9 +571,12 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                 stats->segments = c.segments, stats->node_visits = c.node_visits, stats->tri_tests = c.tri_tests;
                 stats->sphere_tests = c.sphere_tests, stats->quad_tests = c.quad_tests;
                 if (getenv("RT_STAGE_DEBUG"))
-                    for (int k = 0; k < 3; ++k)
-                        fprintf(stderr, "[stages] %d: trips %llu lanes/trip %.1f\n", k, c.stage_trips[k],
-                                c.stage_trips[k] ? (double)c.stage_lanes[k] / (double)c.stage_trips[k] : 0.0);
+                    for (int k = 0; k < 4; ++k)
+                        fprintf(stderr, "[stages] %d: trips %llu lanes/trip %.1f cycles/trip %.0f total Gcycles %.2f\n", k,
+                                c.stage_trips[k],
+                                c.stage_trips[k] ? (double)c.stage_lanes[k] / (double)c.stage_trips[k] : 0.0,
+                                c.stage_trips[k] ? (double)c.stage_cycles[k] / (double)c.stage_trips[k] : 0.0,
+                                (double)c.stage_cycles[k] * 1e-9);
             }
         }
         return 0;

@@ -71,7 +71,7 @@ struct DevCounters {  // one instance in HBM, bumped with one atomic per wave at
     unsigned long long samples, segments, node_visits, tri_tests, sphere_tests, quad_tests;
     unsigned int work;  // chunk cursor of the persistent kernel
     unsigned int pad;
-    unsigned long long stage_trips[8], stage_lanes[8];  // persistent kernel, counting build: per stage
+    unsigned long long stage_trips[8], stage_lanes[8], stage_cycles[8];  // persistent kernels, counting build: per stage
 };
 
 }  // namespace rt

@@ -11,6 +11,13 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
                                     uint32_t* work_counter, bool stats, hipStream_t stream);
 // bytes of the tile-planar accumulator the persistent kernel adds into (d_acc above)
 size_t persistent_acc_bytes(uint32_t width, uint32_t height);
+// tile-planar accumulator -> row-major interleaved framebuffer
+hipError_t launch_resolve(const float* d_acc, uint32_t width, uint32_t height, float* d_rgb_sum, hipStream_t stream);
+// pooled persistent kernel (render_pool.hip): same arguments; false = use launch_render_persistent instead
+bool pool_kernel_supports(uint32_t width, uint32_t height, uint32_t tree_depth);
+hipError_t launch_render_pool(const DevScene& sc, const DevRenderParams& rp, uint32_t tree_depth, uint32_t n_cus,
+                              float* d_acc, float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter,
+                              bool stats, hipStream_t stream);
 hipError_t launch_tonemap(const float* d_rgb_sum, uint32_t n_values, double n_samples, uint8_t* d_out,
                           hipStream_t stream);
 hipError_t launch_primary64(const DevScene& sc, uint32_t width, uint32_t height, int32_t* d_prim_id, double* d_t,

@@ -6,9 +6,11 @@
 // a lane whose path ended takes the next sample at once (ballot + mbcnt, no LDS, no barrier), so every lane
 // traces one ray segment per loop trip whatever the mix of sky, ground and mesh pixels in the tile, and a
 // wave that drew cheap tiles simply pulls more chunks (no static pixel ownership, no tail of heavy waves).
-// A finished path adds its radiance to the f32 framebuffer with three float atomics — a path contributes
-// exactly once (at a light, at the sky, or nothing), so that is 12 B of atomic traffic per sample and the
-// only HBM traffic besides scene fetches.
+// A finished path adds its radiance with three float atomics — a path contributes exactly once (at a light,
+// at the sky, or nothing) — into a tile-planar accumulator acc[tile][rgb][64] (the 64 pixels of a chunk's tile
+// are 256 contiguous bytes per component, so a wave's atomics fall into few cache lines); resolve_kernel then
+// writes the caller's row-major interleaved framebuffer.  That is 12 B of atomic traffic per sample plus
+// 24 B per pixel, and the only HBM traffic besides scene fetches.
 #include <algorithm>
 #include <cstdlib>
 
@@ -71,6 +73,8 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     TraceStats st;
     uint32_t n_segments = 0;
     uint32_t trips[3] = {0, 0, 0}, lanes_on[3] = {0, 0, 0};  // counting build: stage occupancy
+    unsigned long long cycles[3] = {0, 0, 0}, t_begin = 0;
+    int stage_run = 0;
 
     // Every trip runs ONE stage for the lanes waiting in it — the stage most lanes wait in — so the lanes that
     // execute a trip all do the same small piece of work (one node, one primitive, or one shade+raygen),
@@ -83,21 +87,22 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         if ((n_shade | n_leaf | n_node) == 0) break;  // every lane idle: no paths in flight, no work left
 
         const bool run_shade = n_shade >= plan.shade_threshold || (n_node | n_leaf) == 0;
+        if (STATS) t_begin = __builtin_readcyclecounter();
         if (!run_shade && n_node >= n_leaf) {
-            if (STATS) trips[0]++, lanes_on[0] += n_node;
+            if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
 #pragma unroll 1
             for (int k = 0; k < RT_NODE_STEPS; ++k)
                 if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, kBlock, sp, st);
         } else if (!run_shade) {
-            if (STATS) trips[1]++, lanes_on[1] += n_leaf;
+            if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (node < 0) {
                 int slot = ~node;  // leaves hold at most 4 slots (render tree), so the whole leaf is one trip
                 while (!prim_step<STATS>(sc, ray, sr, 0.001f, slot, best, st)) ++slot;
                 node = stack_pop(stack, kBlock, sp);
             }
         } else {
-            if (STATS) trips[2]++, lanes_on[2] += n_shade;
+            if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
             const bool mine = node == kStageShade;
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
@@ -170,6 +175,10 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                 }
             }
         }
+        if (STATS) {
+            const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
+            for (int k = 0; k < 3; ++k) cycles[k] += stage_run == k ? dt : 0ull;
+        }
     }
 
     if (STATS) {
@@ -182,6 +191,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             for (int k = 0; k < 3; ++k) {
                 atomicAdd(&counters->stage_trips[k], (unsigned long long)trips[k]);
                 atomicAdd(&counters->stage_lanes[k], (unsigned long long)lanes_on[k]);
+                atomicAdd(&counters->stage_cycles[k], cycles[k]);
             }
     }
 }
@@ -233,12 +243,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     hipError_t e = hipMemsetAsync(d_acc, 0, persistent_acc_bytes(rp.width, rp.height), stream);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-    const uint32_t n_pixels = rp.width * rp.height;
-    if (plan.n_chunks == 0) {
-        hipLaunchKernelGGL(resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, d_acc, rp.width, rp.height,
-                           plan.tiles_x, d_rgb_sum);
-        return hipGetLastError();
-    }
+    if (plan.n_chunks == 0) return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);
     // Enough blocks to fill every CU at the occupancy the kernel's registers and LDS allow; surplus blocks are
     // harmless (they start when a slot frees up and find the counter exhausted).
     const uint32_t blocks = std::min<uint32_t>(n_cus * 8u, (plan.n_chunks + 3u) / 4u);
@@ -248,8 +253,12 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     else if (tree_depth <= 64) e = launch_stack<64>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     else return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, d_acc, rp.width, rp.height,
-                       plan.tiles_x, d_rgb_sum);
+    return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);
+}
+
+hipError_t launch_resolve(const float* d_acc, uint32_t width, uint32_t height, float* d_rgb_sum, hipStream_t stream) {
+    hipLaunchKernelGGL(resolve_kernel, dim3((width * height + 255u) / 256u), dim3(256), 0, stream, d_acc, width, height,
+                       (width + 7u) >> 3, d_rgb_sum);
     return hipGetLastError();
 }
 

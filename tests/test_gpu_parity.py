@@ -96,7 +96,7 @@ def _check_image(got_sum, want_sum, n, name):
 
 
 @pytest.mark.parametrize("sampler", [0, 1])
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
 @pytest.mark.parametrize("name", SCENES)
 def test_image_matches_golden(ra, scenes, name, kernel, sampler):
     """Same sampler on both sides (0: the reference's rejection loops, 1: the direct maps): GPU and oracle then
@@ -118,7 +118,7 @@ def test_image_matches_oracle_higher_spp(scenes, ref, name, w, h, sn):
     o = ref.RefScene.from_yaml(scene_path(name), w / h)
     for sampler in (0, 1):
         want, _ = o.render(w, h, sn, threads=16, sampler=sampler)
-        for kernel in (0, 1):
+        for kernel in (0, 1, 2):
             img, _ = scenes(name, w / h).render(w, h, sn, kernel=kernel, sampler=sampler)
             _check_image(img, want, sn * sn, name)
 
@@ -136,14 +136,16 @@ def test_kernels_agree_and_are_repeatable(scenes):
     a, _ = s.render(192, 108, 4, kernel=0)
     b, _ = s.render(192, 108, 4, kernel=0)
     c, _ = s.render(192, 108, 4, kernel=1)
+    d, _ = s.render(192, 108, 4, kernel=2)
     assert np.allclose(a, b, rtol=1e-5, atol=1e-6)   # same binary, same samples: only the f32 sum order may differ
-    assert _same_image(a, c, 16)                     # same paths in both kernel organisations
+    assert _same_image(a, c, 16)                     # same paths in all three kernel organisations
+    assert _same_image(a, d, 16)
 
 
 def test_strata_slices_sum_to_the_full_frame(scenes):
     """Multi-GPU sharding: strata k = g mod N on GPU g; the union is the single-GPU sample set."""
     s = scenes("teapot", 16 / 9)
-    for kernel in (0, 1):
+    for kernel in (0, 1, 2):
         full, st = s.render(160, 90, 4, kernel=kernel)
         parts = [s.render(160, 90, 4, kernel=kernel, stratum_begin=g, stratum_step=3) for g in range(3)]
         assert sum(p[1].samples for p in parts) == st.samples
