@@ -89,6 +89,7 @@ struct rt_scene {
     // flattened host copies (kept for host-only inspection and tests)
     std::vector<float4> nodes, prims, tri_shade, materials;
     std::vector<int4> loose;
+    std::vector<uint4> loose_rec;
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
     std::vector<Node64> nodes64;
@@ -215,7 +216,6 @@ void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
     s.info.max_leaf_size = bvh.max_leaf_size;
 }
 
-constexpr size_t kMaxLoose = 16;      // at most this many spheres+quads are tested by every ray ("loose")
 constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured: 2 beats 4 and 8 by 4-5 %)
 
 // Render tree + loose list -> f32 arrays of the render kernels.
@@ -328,6 +328,8 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
             float4* sh = &s.tri_shade[3 * slot];
             for (int k = 0; k < 3; ++k) sh[k] = {(float)t.n[k][0], (float)t.n[k][1], (float)t.n[k][2], 0};
             sh[0].w = int_bits(t.material);
+            if ((uint32_t)t.material >= (1u << (32 - kMetaIndexShift))) throw std::runtime_error("material id out of range");
+            p[0].w = uint_bits(meta | ((uint32_t)t.material << kMetaIndexShift));
         } else {
             meta |= (uint32_t)ref.index << kMetaIndexShift;
             p[0].w = uint_bits(meta);
@@ -354,6 +356,16 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         o[3] = q.d;
         o[7] = A.x, o[8] = A.y, o[9] = A.z, o[10] = B.x, o[11] = B.y, o[12] = B.z;
         s.quad_mat[i] = q.material;
+    }
+    // loose records: header + the sphere's / quad's doubles, self-contained (staged in LDS by the kernels)
+    s.loose_rec.assign(kLooseRecQuads * std::max<size_t>(s.loose.size(), 1), uint4{0, 0, 0, 0});
+    for (size_t i = 0; i < s.loose.size(); ++i) {
+        const int4& l = s.loose[i];
+        uint4* rec = &s.loose_rec[kLooseRecQuads * i];
+        const int32_t mat = l.x == RT_SURF_SPHERE ? s.sphere_mat[l.y] : s.quad_mat[l.y];
+        rec[0] = uint4{(uint32_t)l.x, (uint32_t)l.y, (uint32_t)l.z, (uint32_t)mat};
+        if (l.x == RT_SURF_SPHERE) std::memcpy(rec + 1, &s.spheres[4 * l.y], 4 * sizeof(double));
+        else std::memcpy(rec + 1, &s.quads[16 * l.y], 13 * sizeof(double));
     }
     s.materials.resize(d.n_materials);
     s.mat_kind.resize(d.n_materials);
@@ -479,6 +491,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.prims = upload(*s, s->prims);
         s->dev.tri_shade = upload(*s, s->tri_shade);
         s->dev.loose = upload(*s, s->loose);
+        s->dev.loose_rec = upload(*s, s->loose_rec);
         s->dev.spheres = upload(*s, s->spheres);
         s->dev.quads = upload(*s, s->quads);
         s->dev.sphere_mat = upload(*s, s->sphere_mat);
@@ -577,6 +590,11 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                                 c.stage_trips[k] ? (double)c.stage_lanes[k] / (double)c.stage_trips[k] : 0.0,
                                 c.stage_trips[k] ? (double)c.stage_cycles[k] / (double)c.stage_trips[k] : 0.0,
                                 (double)c.stage_cycles[k] * 1e-9);
+                if (getenv("RT_STAGE_DEBUG") && c.stage_trips[2])
+                    fprintf(stderr, "[shade trip] bounce+accumulate %.0f, regenerate %.0f, loose+bounds %.0f cycles/trip\n",
+                            (double)c.stage_cycles[4] / (double)c.stage_trips[2],
+                            (double)c.stage_cycles[5] / (double)c.stage_trips[2],
+                            (double)c.stage_cycles[6] / (double)c.stage_trips[2]);
             }
         }
         return 0;

@@ -225,33 +225,41 @@ constexpr int kTraversalDone = 0x7fffffff;  // "node" value once the stack has r
 
 struct Closest {
     HitRec h;
-    int rank;  // rank of h.slot's surface (ties)
+    int rank;       // rank of h.slot's surface (ties)
+    uint32_t meta;  // meta word of h.slot (tree hits): type and material / index for the shade step
 };
 __device__ __forceinline__ void closest_reset(Closest& c) {
     c.h.t = __builtin_inff();
     c.h.slot = -1;
     c.h.bu = c.h.bv = 0.f;
     c.rank = -1;
+    c.meta = 0u;
 }
 
-// Loose spheres/quads: every lane tests the same primitive at the same time (no divergence, the records come
-// through the scalar cache); f64 because radius-1000 spheres and 555-unit walls need it.
+// Loose spheres/quads: every lane tests the same primitive at the same time (no divergence); f64 because
+// radius-1000 spheres and 555-unit walls need it.  `recs` are the self-contained records of
+// DevScene::loose_rec — in LDS for the persistent kernels (one broadcast read per 16 B, no dependent
+// global round trips inside the loop), in global memory for the others.
+__device__ __forceinline__ const double* loose_data(const uint4* recs, uint32_t i) {
+    return (const double*)(recs + kLooseRecQuads * i + 1);
+}
 template <bool STATS>
-__device__ __forceinline__ void loose_hits(const DevScene& sc, const Ray& ray, float tmin, Closest& best, TraceStats& st) {
+__device__ __forceinline__ void loose_hits(const uint4* recs, uint32_t n_loose, const Ray& ray, float tmin,
+                                           Closest& best, TraceStats& st) {
     const D3 dd = d3(ray.d);
-    for (uint32_t i = 0; i < sc.n_loose; ++i) {
-        const int4 m = sc.loose[i];
+    for (uint32_t i = 0; i < n_loose; ++i) {
+        const uint4 m = recs[kLooseRecQuads * i];
         double t;
-        if (m.x == 0) {
+        if (m.x == 0u) {
             if (STATS) st.spheres++;
-            t = sphere_root(sc.spheres + 4 * m.y, ray.o, dd, (double)tmin, (double)best.h.t);
+            t = sphere_root(loose_data(recs, i), ray.o, dd, (double)tmin, (double)best.h.t);
         } else {
             if (STATS) st.quads++;
-            t = quad_root(sc.quads + 16 * m.y, ray.o, dd, (double)tmin, (double)best.h.t);
+            t = quad_root(loose_data(recs, i), ray.o, dd, (double)tmin, (double)best.h.t);
         }
         const float tf = (float)t;
-        if (tf >= tmin && (tf < best.h.t || (tf == best.h.t && m.z > best.rank))) {
-            best.h.t = tf, best.h.slot = -2 - (int)i, best.rank = m.z;
+        if (tf >= tmin && (tf < best.h.t || (tf == best.h.t && (int)m.z > best.rank))) {
+            best.h.t = tf, best.h.slot = -2 - (int)i, best.rank = (int)m.z;
             hit_set_t64(best.h, t);
         }
     }
@@ -368,7 +376,7 @@ __device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, co
     if (t >= tmin && t <= best.h.t) {
         const int rank = __float_as_int(p1.w);
         if (t < best.h.t || rank > best.rank) {
-            best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank;
+            best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank, best.meta = meta;
             if (type != 1u) hit_set_t64(best.h, t64);
         }
     }
@@ -381,7 +389,7 @@ __device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& r
                                                 int stack_stride, TraceStats& st) {
     Closest best;
     closest_reset(best);
-    loose_hits<STATS>(sc, ray, tmin, best, st);
+    loose_hits<STATS>(sc.loose_rec, sc.n_loose, ray, tmin, best, st);
     if (!sc.has_tree) return best.h;
     const SlabRay r = slab_ray(ray);
     int sp = 0;
@@ -402,24 +410,29 @@ __device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (2.0f * dot(v, n)
 // One bounce (one iteration of the loop at scene/mod.rs:103-125).  `lsum` gathers radiance in the forward
 // form  L += T*emitted; T *= albedo  (equal to resolve_color's back-to-front fold).  Returns whether the
 // path continues; `depth` follows the reference's counter including the metal re-sampling quirk (Q1).
+// `meta` is the hit slot's meta word (Closest::meta; tree hits only), `recs` the loose records as in loose_hits.
 template <bool DIRECT>
-__device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const HitRec& hit, float tmin, Rng& rng,
-                                             F3& thr, F3& lsum, uint32_t& depth, uint32_t max_depth) {
+__device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* recs, Ray& ray, const HitRec& hit,
+                                             uint32_t meta, float tmin, Rng& rng, F3& thr, F3& lsum, uint32_t& depth,
+                                             uint32_t max_depth) {
     if (hit.slot == -1) {  // escaped: (0, background), scene/mod.rs:122
         lsum = lsum + thr * f3(sc.background);
         return false;
     }
+    // type and material first: the material fetch then overlaps the normal fetch
     uint32_t type, index;
+    int mat;
     if (hit.slot >= 0) {
-        const uint32_t meta = __float_as_uint(sc.prims[3 * hit.slot].w);
         type = meta & kMetaTypeMask, index = meta >> kMetaIndexShift;
+        mat = type == 1u ? (int)index : (type == 0u ? sc.sphere_mat[index] : sc.quad_mat[index]);
     } else {
-        const int4 m = sc.loose[-2 - hit.slot];
-        type = (uint32_t)m.x, index = (uint32_t)m.y;
+        const uint4 m = recs[kLooseRecQuads * (uint32_t)(-2 - hit.slot)];
+        type = m.x, index = m.y, mat = (int)m.w;
     }
+    const float4 m = sc.materials[mat];
+    const int kind = sc.mat_kind[mat];
     const D3 dd = d3(ray.d);
     F3 n;
-    int mat;
     D3 p;
     if (type == 1u) {
         const float4 s0 = sc.tri_shade[3 * hit.slot + 0];
@@ -427,26 +440,28 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
         const float4 s2 = sc.tri_shade[3 * hit.slot + 2];
         // un-normalised barycentric blend (Q3), surfaces.rs:277
         n = hit.bu * f3(s1) + hit.bv * f3(s2) + (1.0f - hit.bu - hit.bv) * f3(s0);
-        mat = __float_as_int(s0.w);
         p = ray.o + (double)hit.t * dd;
-    } else if (type == 0u) {
-        const double* spd = sc.spheres + 4 * index;
-        p = ray.o + hit_get_t64(hit) * dd;  // the f64 root (hit.t is its f32 rounding)
-        D3 nn = (1.0 / spd[3]) * (p - d3(spd));  // signed radius: a negative one flips the normal
-        n = tof(nn);
-        mat = sc.sphere_mat[index];
     } else {
-        const double* qd = sc.quads + 16 * index;
-        p = ray.o + hit_get_t64(hit) * dd;
-        n = tof(d3(qd));
-        mat = sc.quad_mat[index];
+        p = ray.o + hit_get_t64(hit) * dd;  // the f64 root (hit.t is its f32 rounding)
+        double c[4];                        // sphere: c.xyz r; quad: normal.xyz d
+        if (hit.slot >= 0) {
+            const double* g = type == 0u ? sc.spheres + 4 * index : sc.quads + 16 * index;
+            c[0] = g[0], c[1] = g[1], c[2] = g[2], c[3] = g[3];
+        } else {
+            const double* l = loose_data(recs, (uint32_t)(-2 - hit.slot));
+            c[0] = l[0], c[1] = l[1], c[2] = l[2], c[3] = l[3];
+        }
+        if (type == 0u) {
+            D3 nn = (1.0 / c[3]) * (p - d3(c));  // signed radius: a negative one flips the normal
+            n = tof(nn);
+        } else {
+            n = tof(d3(c));
+        }
     }
     // Hit::new, trace.rs:59-76: front face from the (shading) normal (Q4)
     const bool front = dot(ray.d, n) < 0.0f;
     if (!front) n = neg(n);
 
-    const float4 m = sc.materials[mat];
-    const int kind = sc.mat_kind[mat];
     const F3 albedo = f3(m);
     if (kind == 3) {  // DiffuseLight: emits on both faces, never scatters (material.rs:66-72, 94)
         lsum = lsum + thr * albedo;

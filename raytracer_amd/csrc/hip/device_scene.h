@@ -6,11 +6,14 @@
 
 namespace rt {
 
-// prim meta word (prims[3*slot].w bits): type in bits 0-1, last-in-leaf in bit 2, type-local index above.
+// prim meta word (prims[3*slot].w bits): type in bits 0-1, last-in-leaf in bit 2; above them the material id
+// (triangles) or the type-local index (spheres, quads).
 constexpr uint32_t kMetaTypeMask = 3u;
 constexpr uint32_t kMetaLast = 4u;
 constexpr int kMetaIndexShift = 3;
 constexpr int kNoChild = 0x7fffffff;  // "empty" child of the synthetic root when the tree is one leaf
+constexpr uint32_t kMaxLoose = 16;    // at most this many spheres+quads are tested by every ray ("loose")
+constexpr uint32_t kLooseRecQuads = 8;  // uint4 per loose record: {type, index, rank, material} + 14 doubles
 
 // f64 records for the exact-parity kernel (array of structs; speed is irrelevant there).
 struct Node64 {
@@ -41,6 +44,9 @@ struct DevScene {
                                 //   reference tree's in-order leaf sequence (decides equal-t ties)
     const float4* tri_shade;    // 3 per leaf slot: vertex normals n0 n1 n2; [0].w = material id bits
     const int4* loose;          // spheres/quads tested by every ray before traversal: type, index, rank, surface id
+    const uint4* loose_rec;     // the same, self-contained (kLooseRecQuads uint4 each): {type, index, rank, material},
+                                //   then the sphere's c.xyz r or the quad's normal d q A B as doubles; the
+                                //   persistent kernels stage these in LDS
     uint32_t n_loose;
     uint32_t has_tree;          // 0: no surface lives in the render tree (all are loose)
     float tree_lo[3], tree_hi[3];  // bounds of the render tree (inflated like the node boxes)

@@ -48,7 +48,10 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
     __shared__ int lds_stack[STACK * kBlock];
+    __shared__ uint4 lds_loose[kMaxLoose * kLooseRecQuads];
     int* stack = lds_stack + threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < sc.n_loose * kLooseRecQuads; i += kBlock) lds_loose[i] = sc.loose_rec[i];
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t seed = ((uint64_t)rp.seed_hi << 32) | rp.seed_lo;
 
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     uint32_t n_segments = 0;
     uint32_t trips[3] = {0, 0, 0}, lanes_on[3] = {0, 0, 0};  // counting build: stage occupancy
     unsigned long long cycles[3] = {0, 0, 0}, t_begin = 0;
+    unsigned long long sub_cycles[3] = {0, 0, 0};  // shade trip split: bounce+accumulate, regenerate, loose+bounds
     int stage_run = 0;
 
     // Every trip runs ONE stage for the lanes waiting in it — the stage most lanes wait in — so the lanes that
@@ -104,9 +108,11 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         } else {
             if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
             const bool mine = node == kStageShade;
+            unsigned long long t_part = 0;
+            if (STATS) t_part = __builtin_readcyclecounter();
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
-                alive = shade_bounce<DIRECT>(sc, ray, best.h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+                alive = shade_bounce<DIRECT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth, rp.max_depth);
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
                     float* a = acc + (size_t)(pix >> 6) * 192u + (pix & 63u);
@@ -114,6 +120,10 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                     atomicAdd(a + 64, lsum.y);
                     atomicAdd(a + 128, lsum.z);
                 }
+            }
+            if (STATS) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                sub_cycles[0] += t - t_part, t_part = t;
             }
             // ---- regenerate: lanes without a path take the next samples of the chunk (uniform control flow)
             unsigned long long need = __ballot(mine && !alive);
@@ -157,13 +167,17 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                 next_j += min((uint32_t)__popcll(need), avail);
                 need = __ballot(mine && !alive);
             }
+            if (STATS) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                sub_cycles[1] += t - t_part, t_part = t;
+            }
             // ---- start the next segment's trace: loose spheres/quads now (all these lanes in lockstep), the
             // tree through the node/leaf stages
             if (mine) {
                 if (alive) {
                     if (STATS) n_segments++;
                     closest_reset(best);
-                    loose_hits<STATS>(sc, ray, 0.001f, best, st);
+                    loose_hits<STATS>(lds_loose, sc.n_loose, ray, 0.001f, best, st);
                     if (sc.has_tree) {
                         sr = slab_ray(ray);
                         sp = 0;
@@ -174,10 +188,11 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                     node = kStageIdle;
                 }
             }
+            if (STATS) sub_cycles[2] += __builtin_readcyclecounter() - t_part;
         }
         if (STATS) {
-            const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
-            for (int k = 0; k < 3; ++k) cycles[k] += stage_run == k ? dt : 0ull;
+            const unsigned long long t_end = __builtin_readcyclecounter();
+            for (int k = 0; k < 3; ++k) cycles[k] += stage_run == k ? t_end - t_begin : 0ull;
         }
     }
 
@@ -192,6 +207,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                 atomicAdd(&counters->stage_trips[k], (unsigned long long)trips[k]);
                 atomicAdd(&counters->stage_lanes[k], (unsigned long long)lanes_on[k]);
                 atomicAdd(&counters->stage_cycles[k], cycles[k]);
+                atomicAdd(&counters->stage_cycles[4 + k], sub_cycles[k]);
             }
     }
 }

@@ -26,7 +26,7 @@
 namespace rt {
 
 #ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS 80
+#define RT_POOL_SLOTS 64
 #endif
 #ifndef RT_POOL_WAVES
 #define RT_POOL_WAVES 3  // waves per SIMD the register budget is set for (LDS allows 12 one-wave blocks per CU)
@@ -86,8 +86,10 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void render_pool_kernel(DevScene
     __shared__ int lds_stack[STACK * 64];
     __shared__ uint4 pool[kPool * 5];
     __shared__ unsigned char q_shade[kPool], q_trace[kPool], q_free[kPool];
+    __shared__ uint4 lds_loose[kMaxLoose * kLooseRecQuads];
     const uint32_t lane = threadIdx.x;
     int* stack = lds_stack + lane;
+    for (uint32_t i = lane; i < sc.n_loose * kLooseRecQuads; i += 64u) lds_loose[i] = sc.loose_rec[i];
     const uint64_t seed = ((uint64_t)rp.seed_hi << 32) | rp.seed_lo;
 
     // every slot starts as a record without a path, queued for the shade stage (which starts paths)
@@ -162,7 +164,8 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void render_pool_kernel(DevScene
             // shade the finished segment (scene/mod.rs:104-123)
             if (alive2) {
                 F3 lsum = {0.f, 0.f, 0.f};
-                alive2 = shade_bounce<DIRECT>(sc, r2, h2, 0.001f, g2, thr2, lsum, depth2, rp.max_depth);
+                const uint32_t meta2 = h2.slot >= 0 ? __float_as_uint(sc.prims[3 * h2.slot].w) : 0u;
+                alive2 = shade_bounce<DIRECT>(sc, lds_loose, r2, h2, meta2, 0.001f, g2, thr2, lsum, depth2, rp.max_depth);
                 if (!alive2 && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     float* a = acc + (size_t)(pix2 >> 6) * 192u + (pix2 & 63u);
                     atomicAdd(a, lsum.x);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void render_pool_kernel(DevScene
                 dp2 = kDeadPath;
                 if (alive2) {
                     if (STATS) n_segments++;
-                    loose_hits<STATS>(sc, r2, 0.001f, b2, st);
+                    loose_hits<STATS>(lds_loose, sc.n_loose, r2, 0.001f, b2, st);
                     dest = 0;
                     if (sc.has_tree && hits_tree_bounds(sc, slab_ray(r2), 0.001f, b2.h.t)) dest = 1;
                     dp2 = (depth2 << kPixBits) | pix2;

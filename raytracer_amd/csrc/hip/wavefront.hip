@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kWBlock) void wf_shade(DevScene sc, DevRenderParams
             F3 thr = {b.thr[p], b.thr[c + p], b.thr[2 * c + p]};
             F3 lsum = {0.f, 0.f, 0.f};
             uint32_t depth = b.depth[p];
-            alive = shade_bounce<DIRECT>(sc, ray, h, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+            const uint32_t meta = h.slot >= 0 ? __float_as_uint(sc.prims[3 * h.slot].w) : 0u;
+            alive = shade_bounce<DIRECT>(sc, sc.loose_rec, ray, h, meta, 0.001f, rng, thr, lsum, depth, rp.max_depth);
             if (alive) {
                 store_ray(b, p, ray);
                 b.thr[p] = thr.x, b.thr[c + p] = thr.y, b.thr[2 * c + p] = thr.z;
