@@ -311,7 +311,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     std::vector<uint8_t> last(std::max<size_t>(n_slots, 1), 0);
     for (const BvhNode& n : rb.nodes)
         if (n.is_leaf() && n.count > 0) last[n.first + n.count - 1] = 1;
-    s.prims.assign(3 * std::max<size_t>(n_slots, 1), float4{0, 0, 0, 0});
+    s.prims.assign(3 * (std::max<size_t>(n_slots, 1) + 1), float4{0, 0, 0, 0});  // + one slot of padding (leaf_step)
     s.tri_shade.assign(3 * std::max<size_t>(n_slots, 1), float4{0, 0, 0, 0});
     s.slot_surface.assign(std::max<size_t>(n_slots, 1), -1);
     for (size_t slot = 0; slot < n_tree; ++slot) {
@@ -471,9 +471,9 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         flatten_reference64(*desc, *s);
         flatten_render(*desc, *s);
         s->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (s->stack_depth > 64)
+        if (s->stack_depth > 56)
             throw std::runtime_error("BVH depth " + std::to_string(s->stack_depth) +
-                                     " exceeds the traversal stack (64 levels)");
+                                     " exceeds the traversal stack (56 levels)");
         fill_camera(*desc, s->dev);
         s->dev.n_slots = (uint32_t)s->slot_surface.size();
         s->dev.n_loose = (uint32_t)s->loose.size();

@@ -101,8 +101,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         } else if (!run_shade) {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (node < 0) {
-                int slot = ~node;  // leaves hold at most 4 slots (render tree), so the whole leaf is one trip
-                while (!prim_step<STATS>(sc, ray, sr, 0.001f, slot, best, st)) ++slot;
+                leaf_step<STATS>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = stack_pop(stack, kBlock, sp);
             }
         } else {
@@ -266,7 +265,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // near-first traversal keeps at most (depth - 1) deferred children
     if (tree_depth <= 24) e = launch_stack<24>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     else if (tree_depth <= 40) e = launch_stack<40>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
-    else if (tree_depth <= 64) e = launch_stack<64>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
+    else if (tree_depth <= 56) e = launch_stack<56>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     else return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
     if (e != hipSuccess) return e;
     return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);

@@ -283,8 +283,7 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void render_pool_kernel(DevScene
         } else {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (node < 0) {
-                int slot = ~node;
-                while (!prim_step<STATS>(sc, ray, sr, 0.001f, slot, best, st)) ++slot;
+                leaf_step<STATS>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = stack_pop(stack, 64, sp);
             }
         }
