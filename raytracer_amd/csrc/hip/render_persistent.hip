@@ -42,6 +42,21 @@ struct PersistentPlan {
 constexpr int kStageShade = kTraversalDone;
 constexpr int kStageIdle = 0x7ffffffe;
 
+// Adds the wave's LDS tile sums into the tile-planar accumulator (one 256-byte run per component) and clears
+// them.  Called by all 64 lanes.
+__device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc, uint32_t tile, uint32_t lane) {
+    if (tile == 0xffffffffu) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float* g = acc + (size_t)tile * 192u + lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = wacc[64 * c + lane];
+        if (v != 0.f) atomicAdd(g + 64 * c, v);
+        wacc[64 * c + lane] = 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 template <int STACK, bool STATS, bool DIRECT>
 __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
@@ -51,6 +66,11 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     __shared__ uint4 lds_loose[kMaxLoose * kLooseRecQuads];
     int* stack = lds_stack + threadIdx.x;
     for (uint32_t i = threadIdx.x; i < sc.n_loose * kLooseRecQuads; i += kBlock) lds_loose[i] = sc.loose_rec[i];
+    // radiance sums of the tile this wave's current chunk belongs to (3 x 64 floats per wave)
+    __shared__ float lds_acc[(kBlock / 64) * 192];
+    float* wacc = lds_acc + (threadIdx.x >> 6) * 192;
+    wacc[threadIdx.x & 63u] = 0.f, wacc[64 + (threadIdx.x & 63u)] = 0.f, wacc[128 + (threadIdx.x & 63u)] = 0.f;
+    uint32_t acc_tile = 0xffffffffu;  // wave-uniform
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t seed = ((uint64_t)rp.seed_hi << 32) | rp.seed_lo;
@@ -115,9 +135,15 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
                     float* a = acc + (size_t)(pix >> 6) * 192u + (pix & 63u);
-                    atomicAdd(a, lsum.x);
-                    atomicAdd(a + 64, lsum.y);
-                    atomicAdd(a + 128, lsum.z);
+                    if ((pix >> 6) == acc_tile) {  // the wave's current tile: sum in LDS, flushed once per chunk
+                        atomicAdd(wacc + (pix & 63u), lsum.x);
+                        atomicAdd(wacc + 64 + (pix & 63u), lsum.y);
+                        atomicAdd(wacc + 128 + (pix & 63u), lsum.z);
+                    } else {  // a path that outlived its chunk
+                        atomicAdd(a, lsum.x);
+                        atomicAdd(a + 64, lsum.y);
+                        atomicAdd(a + 128, lsum.z);
+                    }
                 }
             }
             if (STATS) {
@@ -138,6 +164,8 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                     // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
                     chunk_group = c / plan.n_tiles;
                     chunk_tile = c - chunk_group * plan.n_tiles;
+                    flush_tile(acc, wacc, acc_tile, lane);
+                    acc_tile = chunk_tile;
                     const uint32_t strata_here = min(kChunkStrata, plan.my_strata - chunk_group * kChunkStrata);
                     chunk_total = 64u * strata_here;
                     next_j = 0;
@@ -194,6 +222,8 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             for (int k = 0; k < 3; ++k) cycles[k] += stage_run == k ? t_end - t_begin : 0ull;
         }
     }
+
+    flush_tile(acc, wacc, acc_tile, lane);
 
     if (STATS) {
         atomicAdd(&counters->segments, (unsigned long long)n_segments);
