@@ -54,6 +54,21 @@ def cache_bytes_per_sample(st) -> float:
     return (st.node_visits * 64 + st.tri_tests * 84 + st.sphere_tests * 16 + st.quad_tests * 72) / n
 
 
+def pmc_traffic(workload: str):
+    """Memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE + WRITE_SIZE, KB -> bytes), when they were taken on this very workload; else None.  The
+    counters cannot be read from inside the timed process, so this is the profile of the same command."""
+    path = os.path.join(ROOT, "profiles", "r1_final_pmc.json")
+    try:
+        with open(path) as fh:
+            p = json.load(fh)
+    except OSError:
+        return None
+    if p.get("workload") != workload:
+        return None
+    return round((p["FETCH_SIZE_KB"] + p["WRITE_SIZE_KB"]) * 1024.0)
+
+
 def cpu_baseline(scene_file: str, width: int, height: int, sn: int, threads: int):
     """The oracle (the f64 CPU restatement of the reference's render loop, Q1 re-trace cost included) timed on
     this box's host cores on a bounded sample of the same workload: same scene and resolution, sn*sn spp."""
@@ -77,12 +92,12 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--kernel", choices=["persistent", "wavefront"], default="persistent")
+    ap.add_argument("--kernel", choices=["persistent", "wavefront", "pool"], default="persistent")
     ap.add_argument("--sampler", choices=["direct", "reference"], default="direct",
                     help="unit-sphere/disk sampling: loop-free direct maps (default) or the reference's rejection loops; "
                          "same distributions (tests/test_golden.py, tests/test_gpu_parity.py)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sn", type=int, default=6, help="strata per axis of the CPU-baseline sample")
+    ap.add_argument("--cpu-sn", type=int, default=10, help="strata per axis of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--png", default=None, help="rank 0 writes the last frame here")
     args = ap.parse_args()
@@ -109,7 +124,8 @@ def main() -> None:
     scene_file = os.path.join(ROOT, "scenes", f"{args.scene}.yaml")
     w, h = args.width, args.height
     sn = int(np.floor(np.sqrt(args.spp)))  # main.rs:142
-    kernel = ra.RT_KERNEL_PERSISTENT if args.kernel == "persistent" else ra.RT_KERNEL_WAVEFRONT
+    kernel = {"persistent": ra.RT_KERNEL_PERSISTENT, "wavefront": ra.RT_KERNEL_WAVEFRONT,
+              "pool": ra.RT_KERNEL_POOL}[args.kernel]
     sampler = ra.RT_SAMPLER_DIRECT if args.sampler == "direct" else ra.RT_SAMPLER_REFERENCE
     t0 = time.perf_counter()
     desc = ra.load_scene(scene_file, w / h)
@@ -164,29 +180,34 @@ def main() -> None:
     my_samples = last.samples  # samples this rank rendered per step
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved_tflops = fl * my_samples / avg_kernel_s / 1e12
-    # HBM-side traffic the algorithm needs per launch: one 12-byte float-atomic add per finished sample plus the
-    # 12 B/pixel clear (persistent kernel); the wavefront form adds its path-state queues (~216 B per segment).
+    # HBM-side traffic the algorithm needs per launch (persistent kernels): clear of the tile-planar accumulator
+    # (12 B/pixel), one 768-byte flush of a wave's tile sums per chunk of 1024 samples, and the resolve pass
+    # (12 B/pixel read + 12 B/pixel written).  The wavefront form instead adds 12 B per sample directly and
+    # streams its path-state queues (~216 B per segment).
     seg_per_sample = cnt.segments / max(cnt.samples, 1)
-    hbm_bytes = 12.0 * w * h + 12.0 * my_samples
     if kernel == ra.RT_KERNEL_WAVEFRONT:
-        hbm_bytes += 216.0 * seg_per_sample * my_samples
+        hbm_bytes = 12.0 * w * h + 12.0 * my_samples + 216.0 * seg_per_sample * my_samples
+    else:
+        hbm_bytes = 36.0 * w * h + 0.75 * my_samples
 
     if rank == 0:
+        workload = (f"scenes/{args.scene}.yaml {w}x{h} {sn * sn} spp, max_depth 40, "
+                    f"{args.kernel} kernel, {args.sampler} sampler")
         line = {
             "metric": "Msamples/sec (whole node)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"scenes/{args.scene}.yaml {w}x{h} {sn * sn} spp, max_depth 40, "
-                                   f"{args.kernel} kernel, {args.sampler} sampler", "seconds_per_frame": round(elapsed / args.steps, 4),
+            "config": {"workload": workload, "seconds_per_frame": round(elapsed / args.steps, 4),
                        "parallelism": f"strata-sharded x{world}, 1 RCCL sum-reduce/frame" if world > 1 else "1 GPU",
                        "scene_surfaces": int(info.n_surfaces), "render_bvh_nodes": int(info.render_nodes),
                        "render_bvh_depth": int(info.render_depth), "loose_prims": int(info.n_loose),
                        "scene_setup_s": round(setup_s, 3)},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved_tflops, 4), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),
-                         "traffic": None,
-                         "kernel": "render_persistent_kernel" if kernel == ra.RT_KERNEL_PERSISTENT else "wf_extend+wf_shade",
+                         "traffic": pmc_traffic(workload) if world == 1 else None,
+                         "kernel": {ra.RT_KERNEL_PERSISTENT: "render_persistent_kernel", ra.RT_KERNEL_POOL: "render_pool_kernel",
+                                    ra.RT_KERNEL_WAVEFRONT: "wf_extend+wf_shade"}[kernel],
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 3), "flops_per_sample": round(fl, 1),
                          "segments_per_sample": round(seg_per_sample, 3),
                          "node_visits_per_segment": round(cnt.node_visits / max(cnt.segments, 1), 2),

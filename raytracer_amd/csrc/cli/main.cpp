@@ -1,6 +1,6 @@
 // `raytracer` — command line of the reference (clap derive, main.rs:23-66) over the C ABI in include/rt.h.
 // Same flag names, defaults and conflict rule; same stderr "Done in …" line (main.rs:190) and RGB8 PNG
-// (main.rs:192-200).  Extra flags: --gpus N, --kernel persistent|wavefront, --sampler direct|reference, --dump-primary FILE, --json.
+// (main.rs:192-200).  Extra flags: --gpus N, --kernel persistent|wavefront|pool, --sampler direct|reference, --dump-primary FILE, --json.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -51,7 +51,7 @@ void help() {
         "      --no-progress                  Accepted for compatibility\n"
         "      --no-bvh                       Disables the use of the bvh acceleration structure\n"
         "      --gpus <N>                     Shard the strata over N GPUs [default: 1]\n"
-        "      --kernel <persistent|wavefront>\n"
+        "      --kernel <persistent|wavefront|pool>\n"
         "      --sampler <direct|reference>   Unit-sphere/disk sampling: loop-free maps or the reference's rejection loops\n"
         "      --dump-primary <FILE>          Write the f64 primary-hit AOV (int32 ids, then f64 t) and exit\n"
         "      --json                         Print a JSON metrics line on stdout\n"
@@ -103,6 +103,7 @@ Opt parse(int argc, char** argv) {
             std::string v = need(i, "--kernel");
             if (v == "persistent") o.kernel = RT_KERNEL_PERSISTENT;
             else if (v == "wavefront") o.kernel = RT_KERNEL_WAVEFRONT;
+            else if (v == "pool") o.kernel = RT_KERNEL_POOL;
             else usage_error("invalid value '" + v + "' for '--kernel'");
         } else if (key == "--sampler") {
             std::string v = need(i, "--sampler");
