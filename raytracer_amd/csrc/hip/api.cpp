@@ -423,6 +423,8 @@ DevRenderParams make_params(const rt_scene& s, const rt_render_params& p) {
     rp.stratum_step = p.stratum_step ? p.stratum_step : 1;
     rp.seed_lo = (uint32_t)p.seed, rp.seed_hi = (uint32_t)(p.seed >> 32);
     rp.recip_sn = (float)(1.0 / (double)p.sn);
+    // floor(k / sn) == umulhi(k, magic) for every stratum k < sn*sn as long as sn^3 < 2^32
+    rp.sn_magic = p.sn < 1600u ? (uint32_t)((1ull << 32) / p.sn + 1ull) : 0u;
     if (p.sampler != RT_SAMPLER_REFERENCE && p.sampler != RT_SAMPLER_DIRECT) throw std::runtime_error("unknown sampler");
     rp.sampler = (uint32_t)p.sampler;
     return rp;

@@ -68,6 +68,12 @@ __device__ __forceinline__ D3 cross(D3 a, D3 b) {
 }
 __device__ __forceinline__ F3 tof(D3 v) { return {(float)v.x, (float)v.y, (float)v.z}; }
 
+// Hardware approximations (1 ulp) where the reference's f64 sqrt / division is not what bounds the f32 result:
+// the IEEE-exact f32 expansions cost 10-14 instructions each.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // util.rs:15-24 / 26-35.  Two samplers with the same distributions:
 //   DIRECT == false  the reference's rejection loops, same draw order (parity mode: the oracle's default);
 //   DIRECT == true   closed-form maps with a fixed number of draws (2 for a direction or a disk point, 3 for
@@ -78,14 +84,14 @@ __device__ __forceinline__ F3 rng_unit_vector(Rng& r) {  // uniform on the unit 
     if (DIRECT) {
         const float z = 1.0f - 2.0f * rng_u01(r);
         const float turn = rng_u01(r);
-        const float rad = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        const float rad = fast_sqrt(fmaxf(0.0f, 1.0f - z * z));
         return {rad * __builtin_amdgcn_cosf(turn), rad * __builtin_amdgcn_sinf(turn), z};
     }
     while (true) {
         float x = rng_pm1(r), y = rng_pm1(r), z = rng_pm1(r);
         const float l2 = x * x + y * y + z * z;
         if (l2 < 1.0f) {
-            const float inv_len = 1.0f / sqrtf(l2);
+            const float inv_len = fast_rsq(l2);
             return {inv_len * x, inv_len * y, inv_len * z};
         }
     }
@@ -105,7 +111,7 @@ __device__ __forceinline__ F3 rng_in_unit_sphere(Rng& r) {  // uniform in the un
 template <bool DIRECT>
 __device__ __forceinline__ void rng_in_unit_disk(Rng& r, float& x, float& y) {
     if (DIRECT) {
-        const float rad = sqrtf(rng_u01(r));
+        const float rad = fast_sqrt(rng_u01(r));
         const float turn = rng_u01(r);
         x = rad * __builtin_amdgcn_cosf(turn), y = rad * __builtin_amdgcn_sinf(turn);
         return;
@@ -146,7 +152,7 @@ struct TraceStats {
 template <bool DIRECT>
 __device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
                                           uint32_t stratum, Rng& rng) {
-    uint32_t si = stratum / rp.sn, sj = stratum - si * rp.sn;
+    const uint32_t si = rp.sn_magic ? __umulhi(stratum, rp.sn_magic) : stratum / rp.sn, sj = stratum - si * rp.sn;
     float ju = -0.5f + rp.recip_sn * ((float)si + rng_u01(rng));
     float jv = -0.5f + rp.recip_sn * ((float)sj + rng_u01(rng));
     float s = (float)(pi + 1) + ju;  // in pixel units; *hor_px == (centeru + jitteru*pixel_du)*horizontal
@@ -468,7 +474,7 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
             c[0] = l[0], c[1] = l[1], c[2] = l[2], c[3] = l[3];
         }
         if (type == 0u) {
-            D3 nn = (1.0 / c[3]) * (p - d3(c));  // signed radius: a negative one flips the normal
+            D3 nn = rcp64(c[3]) * (p - d3(c));  // signed radius: a negative one flips the normal
             n = tof(nn);
         } else {
             n = tof(d3(c));
@@ -497,14 +503,14 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
             if (++depth >= max_depth) return false;
         }
     } else {  // Dielectric, material.rs:141-181
-        const float ratio = front ? 1.0f / m.w : m.w;
-        const float inv_len = 1.0f / sqrtf(dot(ray.d, ray.d));
+        const float ratio = front ? fast_rcp(m.w) : m.w;
+        const float inv_len = fast_rsq(dot(ray.d, ray.d));
         const F3 ud = inv_len * ray.d;
         const float cos_theta = fminf(dot(neg(ud), n), 1.0f);
-        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        const float sin_theta = fast_sqrt(1.0f - cos_theta * cos_theta);
         bool refl = ratio * sin_theta > 1.0f;
         if (!refl) {  // short-circuit: the uniform is drawn only when refraction is possible
-            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            float r0 = (1.0f - ratio) * fast_rcp(1.0f + ratio);
             r0 = r0 * r0;
             const float c1 = 1.0f - cos_theta;
             const float c2 = c1 * c1;
@@ -514,7 +520,7 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
             dir = reflect(ud, n);
         } else {
             const F3 perp = ratio * (ud + cos_theta * n);
-            const float par = -sqrtf(fabsf(1.0f - dot(perp, perp)));
+            const float par = -fast_sqrt(fabsf(1.0f - dot(perp, perp)));
             dir = perp + par * n;
         }
     }

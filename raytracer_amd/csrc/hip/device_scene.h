@@ -70,6 +70,7 @@ struct DevRenderParams {
     uint32_t stratum_begin, stratum_step, n_strata;  // n_strata = sn*sn
     uint32_t seed_lo, seed_hi;
     float recip_sn;
+    uint32_t sn_magic;  // division of a stratum index by sn as one multiply-high (0: divide)
     uint32_t sampler;  // RT_SAMPLER_*
 };
 
