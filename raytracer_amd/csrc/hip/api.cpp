@@ -90,6 +90,7 @@ struct rt_scene {
     std::vector<float4> nodes, prims, tri_shade, materials;
     std::vector<int4> loose;
     std::vector<uint4> loose_rec;
+    std::vector<double> sphere_gate;
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
     std::vector<Node64> nodes64;
@@ -345,6 +346,24 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         s.spheres[4 * i + 3] = d.spheres[i].radius;
         s.sphere_mat[i] = d.spheres[i].material;
     }
+    // gate of a sphere = box of the reference tree's leaf that holds it (see leaf_gate_hit in device_rt.h)
+    s.sphere_gate.assign(6 * std::max<size_t>(d.n_spheres, 1), 0.0);
+    for (const BvhNode& n : s.bvh.nodes) {
+        if (!n.is_leaf()) continue;
+        for (int32_t k = n.first; k < n.first + n.count; ++k) {
+            const rt_surface_ref& ref = d.surfaces[s.bvh.order[k]];
+            if (ref.type != RT_SURF_SPHERE) continue;
+            for (int a = 0; a < 3; ++a)
+                s.sphere_gate[6 * ref.index + a] = n.box.lo.get(a), s.sphere_gate[6 * ref.index + 3 + a] = n.box.hi.get(a);
+            // a leaf box that encloses the sphere is crossed by every ray that hits the sphere: no test needed
+            const rt_sphere& sp = d.spheres[ref.index];
+            bool encloses = true;
+            for (int a = 0; a < 3; ++a)
+                encloses = encloses && n.box.lo.get(a) <= sp.center[a] - std::fabs(sp.radius) &&
+                           sp.center[a] + std::fabs(sp.radius) <= n.box.hi.get(a);
+            if (encloses) s.sphere_gate[6 * ref.index] = -INFINITY;
+        }
+    }
     s.quads.assign(16 * d.n_quads, 0.0);
     s.quad_mat.resize(d.n_quads);
     for (size_t i = 0; i < d.n_quads; ++i) {
@@ -364,7 +383,10 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         uint4* rec = &s.loose_rec[kLooseRecQuads * i];
         const int32_t mat = l.x == RT_SURF_SPHERE ? s.sphere_mat[l.y] : s.quad_mat[l.y];
         rec[0] = uint4{(uint32_t)l.x, (uint32_t)l.y, (uint32_t)l.z, (uint32_t)mat};
-        if (l.x == RT_SURF_SPHERE) std::memcpy(rec + 1, &s.spheres[4 * l.y], 4 * sizeof(double));
+        if (l.x == RT_SURF_SPHERE) {
+            std::memcpy(rec + 1, &s.spheres[4 * l.y], 4 * sizeof(double));
+            std::memcpy(rec + 3, &s.sphere_gate[6 * l.y], 6 * sizeof(double));
+        }
         else std::memcpy(rec + 1, &s.quads[16 * l.y], 13 * sizeof(double));
     }
     s.materials.resize(d.n_materials);
@@ -495,6 +517,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.loose = upload(*s, s->loose);
         s->dev.loose_rec = upload(*s, s->loose_rec);
         s->dev.spheres = upload(*s, s->spheres);
+        s->dev.sphere_gate = upload(*s, s->sphere_gate);
         s->dev.quads = upload(*s, s->quads);
         s->dev.sphere_mat = upload(*s, s->sphere_mat);
         s->dev.quad_mat = upload(*s, s->quad_mat);

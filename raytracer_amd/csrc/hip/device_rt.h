@@ -202,6 +202,36 @@ __device__ __forceinline__ double sphere_root(const double* sp, D3 o, D3 d, doub
     return -1.0;
 }
 
+// Aabb::hit (trace.rs:131-149) on the box of the reference tree's leaf that holds a negative-radius sphere.
+// Sphere::bounding_box gives such a sphere an inverted box, which adds nothing to its leaf's box: the
+// reference only ever tests it for rays that hit the rest of the leaf (BVHLeafNode::hit, bvh.rs:300-303), and
+// never when it is alone in a leaf.  gate = lo.xyz hi.xyz.
+__device__ __attribute__((noinline)) bool leaf_gate_hit(const double* gate, D3 o, D3 d, double t_min) {
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    double t_max = __builtin_inf();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // 1/d, +-inf for d = 0 like the reference (trace.rs:18)
+        const double inv_d = dd[a] == 0.0 ? __builtin_copysign(__builtin_inf(), dd[a]) : rcp64(dd[a]);
+        double t0 = (gate[a] - oo[a]) * inv_d, t1 = (gate[3 + a] - oo[a]) * inv_d;
+        if (inv_d < 0.0) {
+            const double tmp = t0;
+            t0 = t1, t1 = tmp;
+        }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max < t_min) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ double sphere_root_gated(const double* sp, const double* gate, D3 o, D3 d, double tmin,
+                                                    double tmax) {
+    double t = sphere_root(sp, o, d, tmin, tmax);
+    // gate[0] == -inf: the host found the leaf's box to enclose the sphere, so every hit passes
+    if (t >= 0.0 && sp[3] < 0.0 && gate[0] != -__builtin_inf() && !leaf_gate_hit(gate, o, d, tmin)) t = -1.0;
+    return t;
+}
+
 // Quad, f64 (surfaces.rs:330-354).  alpha = w·(p×v) = p·(v×w), beta = w·(u×p) = p·(w×u).
 __device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double tmin, double tmax) {
     D3 n = d3(q);
@@ -258,7 +288,7 @@ __device__ __forceinline__ void loose_hits(const uint4* recs, uint32_t n_loose, 
         double t;
         if (m.x == 0u) {
             if (STATS) st.spheres++;
-            t = sphere_root(loose_data(recs, i), ray.o, dd, (double)tmin, (double)best.h.t);
+            t = sphere_root_gated(loose_data(recs, i), loose_data(recs, i) + 4, ray.o, dd, (double)tmin, (double)best.h.t);
         } else {
             if (STATS) st.quads++;
             t = quad_root(loose_data(recs, i), ray.o, dd, (double)tmin, (double)best.h.t);
@@ -271,21 +301,19 @@ __device__ __forceinline__ void loose_hits(const uint4* recs, uint32_t n_loose, 
     }
 }
 
-struct SlabRay {  // f32 ray in the form the fma slab test wants
-    F3 o, d;
+struct SlabRay {  // f32 ray in the form the fma slab test wants: 1/d and o/d per axis
     float idx, idy, idz, oodx, oody, oodz;
 };
 __device__ __forceinline__ SlabRay slab_ray(const Ray& ray) {
     SlabRay r;
-    r.o = tof(ray.o);
-    r.d = ray.d;
+    const F3 o = tof(ray.o), d = ray.d;
     // A zero direction component would make lo*inf - o*inf a NaN or a wrongly signed infinity in the fma slab
     // form; clamp |d| away from zero (2^-80) so every slab bound stays finite and correctly ordered.
     const float ooeps = 0x1p-80f;
-    r.idx = __builtin_amdgcn_rcpf(fabsf(r.d.x) > ooeps ? r.d.x : copysignf(ooeps, r.d.x));
-    r.idy = __builtin_amdgcn_rcpf(fabsf(r.d.y) > ooeps ? r.d.y : copysignf(ooeps, r.d.y));
-    r.idz = __builtin_amdgcn_rcpf(fabsf(r.d.z) > ooeps ? r.d.z : copysignf(ooeps, r.d.z));
-    r.oodx = r.o.x * r.idx, r.oody = r.o.y * r.idy, r.oodz = r.o.z * r.idz;
+    r.idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+    r.idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+    r.idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+    r.oodx = o.x * r.idx, r.oody = o.y * r.idy, r.oodz = o.z * r.idz;
     return r;
 }
 
@@ -352,15 +380,15 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
     if (type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
         if (STATS) st.tris++;
         const F3 e1 = f3(p1), e2 = f3(p2);
-        const F3 pvec = cross(r.d, e2);
+        const F3 pvec = cross(ray.d, e2);
         const float det = dot(e1, pvec);
         if (!(-1e-8f < det && det < 1e-8f)) {
             const float inv_det = __builtin_amdgcn_rcpf(det);
-            const F3 tvec = r.o - f3(p0);
+            const F3 tvec = tof(ray.o) - f3(p0);  // the f32 origin is re-derived here rather than kept in registers
             const float u = dot(tvec, pvec) * inv_det;
             if (u >= 0.f && u <= 1.f) {
                 const F3 qvec = cross(tvec, e1);
-                const float v = dot(r.d, qvec) * inv_det;
+                const float v = dot(ray.d, qvec) * inv_det;
                 if (!(v < 0.f || u + v > 1.f)) {
                     const float tt = dot(e2, qvec) * inv_det;
                     if (!(tt < 1e-4f) && tmin <= tt) t = tt, bu = u, bv = v;
@@ -369,7 +397,8 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
         }
     } else if (type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
         if (STATS) st.spheres++;
-        t64 = sphere_root(sc.spheres + 4 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+        t64 = sphere_root_gated(sc.spheres + 4 * (meta >> kMetaIndexShift), sc.sphere_gate + 6 * (meta >> kMetaIndexShift),
+                                ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
         t = (float)t64;
     } else {
         if (STATS) st.quads++;

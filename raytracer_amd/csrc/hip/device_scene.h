@@ -45,12 +45,15 @@ struct DevScene {
     const float4* tri_shade;    // 3 per leaf slot: vertex normals n0 n1 n2; [0].w = material id bits
     const int4* loose;          // spheres/quads tested by every ray before traversal: type, index, rank, surface id
     const uint4* loose_rec;     // the same, self-contained (kLooseRecQuads uint4 each): {type, index, rank, material},
-                                //   then the sphere's c.xyz r or the quad's normal d q A B as doubles; the
+                                //   then the sphere's c.xyz r + gate lo hi or the quad's normal d q A B as doubles; the
                                 //   persistent kernels stage these in LDS
     uint32_t n_loose;
     uint32_t has_tree;          // 0: no surface lives in the render tree (all are loose)
     float tree_lo[3], tree_hi[3];  // bounds of the render tree (inflated like the node boxes)
     const double* spheres;      // 4 per sphere: c.xyz r
+    const double* sphere_gate;  // 6 per sphere: lo.xyz hi.xyz of the reference tree's leaf that holds it; read for
+                                //   negative radii only (their inverted bounding box adds nothing to the leaf's
+                                //   box, so the reference reaches them only through the leaf's other members)
     const double* quads;        // 16 per quad: normal(3) d q(3) A=v×w (3) B=w×u (3) pad(3)
     const int32_t* sphere_mat;  // material id per sphere
     const int32_t* quad_mat;    // material id per quad

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     bool exhausted = false;
 
     // per-lane path + traversal state
-    F3 lsum = {0.f, 0.f, 0.f}, thr = {1.f, 1.f, 1.f};
+    F3 thr = {1.f, 1.f, 1.f};
     Ray ray;
     ray.o = {0., 0., 0.};
     ray.d = {0.f, 0.f, 1.f};
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             if (STATS) t_part = __builtin_readcyclecounter();
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
+                F3 lsum = {0.f, 0.f, 0.f};  // a path contributes once, where it ends
                 alive = shade_bounce<DIRECT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth, rp.max_depth);
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
@@ -186,7 +187,6 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                         rng_init(rng, seed, py * rp.width + px, stratum);
                         ray = camera_ray<DIRECT>(sc, rp, px, rp.height - py - 1u, stratum, rng);
                         thr = {1.f, 1.f, 1.f};
-                        lsum = {0.f, 0.f, 0.f};
                         depth = 0;
                         alive = true;
                     }

@@ -27,6 +27,8 @@ double area(const Aabb& b) {
     return 2.0 * (l.x * l.y + l.y * l.z + l.z * l.x);
 }
 
+constexpr uint32_t kBalancedFromDepth = 32;  // root = 1; 32 + log2(2^24 primitives) = 56 = the kernels' stack
+
 struct RBuilder {
     std::vector<Item> items;
     Bvh* out;
@@ -50,6 +52,25 @@ struct RBuilder {
             cb.lo = vmin(cb.lo, items[i].c), cb.hi = vmax(cb.hi, items[i].c);
         }
         if (n == 1) return leaf(first, n, box, depth);
+        // SAH can peel primitives off one at a time (geometrically shrinking clusters) and grow a tree as deep
+        // as it is large; the kernels' traversal stacks hold 56 levels.  From this depth on split at the
+        // median of the widest centroid axis, which bounds the rest of the descent by log2(n).
+        if (depth >= kBalancedFromDepth) {
+            if (n <= max_leaf) return leaf(first, n, box, depth);
+            int axis = 0;
+            for (int a = 1; a < 3; ++a)
+                if (cb.hi.get(a) - cb.lo.get(a) > cb.hi.get(axis) - cb.lo.get(axis)) axis = a;
+            const size_t mid = first + n / 2;
+            std::nth_element(items.begin() + first, items.begin() + mid, items.begin() + first + n,
+                             [axis](const Item& a, const Item& b) { return a.c.get(axis) < b.c.get(axis); });
+            const int32_t self = (int32_t)out->nodes.size();
+            out->nodes.emplace_back();
+            const int32_t l = build(first, mid - first, depth + 1);
+            const int32_t r = build(mid, first + n - mid, depth + 1);
+            BvhNode& node = out->nodes[self];
+            node.left = l, node.right = r, node.box = box;
+            return self;
+        }
 
         double best_cost = INFINITY;
         int best_axis = -1, best_bin = -1;

@@ -219,3 +219,12 @@ def test_cli_flags(ra):
         assert flag in r.stdout
     r = subprocess.run([exe, "--scene", "/nonexistent.yaml"], capture_output=True, text=True)
     assert r.returncode == 1 and "load scene file '/nonexistent.yaml'" in r.stderr   # main.rs:101
+
+
+def test_render_tree_depth_is_capped_and_small_prims_move_into_the_tree(ra, tmp_path):
+    import synth
+
+    deep = ra.Scene(ra.load_scene(synth.deep_tree(tmp_path, 3000, 0.5), 1.5), ra.RT_DEVICE_NONE).info()
+    assert 41 <= deep.render_depth <= 56  # SAH alone would go ~1500 levels deep on this cluster
+    many = ra.Scene(ra.load_scene(synth.many_prims(tmp_path), 1.5), ra.RT_DEVICE_NONE).info()
+    assert many.n_loose == 0 and many.n_surfaces == 1 + 28 + 2 + 5 + 200
