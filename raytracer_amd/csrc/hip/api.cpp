@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -90,6 +91,7 @@ struct rt_scene {
     std::vector<float4> nodes, prims, tri_shade, materials;
     std::vector<int4> loose;
     std::vector<uint4> loose_rec;
+    std::vector<int32_t> render_ids;  // surfaces that live in the render tree
     std::vector<double> sphere_gate;
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
@@ -219,23 +221,14 @@ void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
 
 constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured: 2 beats 4 and 8 by 4-5 %)
 
-// Render tree + loose list -> f32 arrays of the render kernels.
-void flatten_render(const rt_scene_desc& d, rt_scene& s) {
-    const size_t n_surf = d.n_surfaces;
-    // rank = position in the reference tree's in-order leaf sequence: decides equal-t ties (bvh.rs:272-273,308)
-    std::vector<int32_t> rank(n_surf);
-    for (size_t i = 0; i < n_surf; ++i) rank[s.bvh.order[i]] = (int32_t)i;
-
+// The tree the render kernels traverse: triangles, plus spheres/quads when the scene has too many of them to
+// test "loose".  Independent of the reference-topology tree, so the two builds run side by side.
+void build_render_tree(const rt_scene_desc& d, rt_scene& s) {
     const bool loose_ok = d.n_spheres + d.n_quads <= kMaxLoose;
-    std::vector<int32_t> tree_ids;
-    s.loose.clear();
-    for (size_t i = 0; i < n_surf; ++i) {
-        const rt_surface_ref& ref = d.surfaces[i];
-        if (ref.type != RT_SURF_TRIANGLE && loose_ok)
-            s.loose.push_back(int4{ref.type, ref.index, rank[i], (int32_t)i});
-        else
-            tree_ids.push_back((int32_t)i);
-    }
+    std::vector<int32_t>& tree_ids = s.render_ids;
+    tree_ids.clear();
+    for (size_t i = 0; i < d.n_surfaces; ++i)
+        if (d.surfaces[i].type == RT_SURF_TRIANGLE || !loose_ok) tree_ids.push_back((int32_t)i);
     Bvh& rb = s.render_bvh;
     if (d.use_bvh) {
         build_render_bvh(d, tree_ids, getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : kRenderLeaf, rb);
@@ -254,6 +247,23 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
             rb.max_depth = 1, rb.n_leaves = 1, rb.max_leaf_size = (uint32_t)tree_ids.size();
         }
     }
+}
+
+// Render tree + loose list -> f32 arrays of the render kernels.
+void flatten_render(const rt_scene_desc& d, rt_scene& s) {
+    const size_t n_surf = d.n_surfaces;
+    // rank = position in the reference tree's in-order leaf sequence: decides equal-t ties (bvh.rs:272-273,308)
+    std::vector<int32_t> rank(n_surf);
+    for (size_t i = 0; i < n_surf; ++i) rank[s.bvh.order[i]] = (int32_t)i;
+
+    const bool loose_ok = d.n_spheres + d.n_quads <= kMaxLoose;
+    const std::vector<int32_t>& tree_ids = s.render_ids;
+    s.loose.clear();
+    for (size_t i = 0; i < n_surf; ++i) {
+        const rt_surface_ref& ref = d.surfaces[i];
+        if (ref.type != RT_SURF_TRIANGLE && loose_ok) s.loose.push_back(int4{ref.type, ref.index, rank[i], (int32_t)i});
+    }
+    Bvh& rb = s.render_bvh;
     const size_t n_tree = tree_ids.size();
     s.has_tree = n_tree > 0;
     const FlatTree ft(rb);
@@ -491,7 +501,17 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         validate(*desc);
         auto s = std::make_unique<rt_scene>();
         auto t0 = std::chrono::steady_clock::now();
-        build_bvh(*desc, s->bvh);
+        // a cold process spends ~0.1-0.2 s creating the device context: do that beside the tree builds
+        std::future<void> warm_up;
+        if (device >= 0)
+            warm_up = std::async(std::launch::async, [device]() {
+                if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
+            });
+        {
+            auto render_job = std::async(std::launch::async, [&]() { build_render_tree(*desc, *s); });
+            build_bvh(*desc, s->bvh);
+            render_job.get();
+        }
         flatten_reference64(*desc, *s);
         flatten_render(*desc, *s);
         s->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -508,6 +528,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
             *out = s.release();
             return 0;
         }
+        if (warm_up.valid()) warm_up.get();
         if (device < 0) HIP_CHECK(hipGetDevice(&device));
         s->device = device;
         DeviceGuard guard(device);

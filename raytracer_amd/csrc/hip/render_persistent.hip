@@ -30,6 +30,7 @@ constexpr uint32_t kChunkStrata = 16;  // strata per chunk (a chunk is 64 pixels
 
 struct PersistentPlan {
     int shade_threshold;     // run the shade stage once this many lanes wait in it (or nothing else can run)
+    int node_bias;           // node stage runs when n_node * node_bias >= n_leaf * 4
     uint32_t tiles_x, n_tiles;
     uint32_t my_strata;      // strata this call renders (begin, begin+step, ...)
     uint32_t groups;         // ceil(my_strata / kChunkStrata)
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
 
         const bool run_shade = n_shade >= plan.shade_threshold || (n_node | n_leaf) == 0;
         if (STATS) t_begin = __builtin_readcyclecounter();
-        if (!run_shade && n_node >= n_leaf) {
+        if (!run_shade && n_node * plan.node_bias >= n_leaf * 4) {
             if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
 #pragma unroll 1
@@ -277,6 +278,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
                                     uint32_t* work_counter, bool stats, hipStream_t stream) {
     PersistentPlan plan;
     plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T")) : 40;
+    plan.node_bias = getenv("RT_NODE_BIAS") ? atoi(getenv("RT_NODE_BIAS")) : 3;
     plan.tiles_x = (rp.width + 7u) >> 3;
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
     plan.my_strata =

@@ -1,6 +1,7 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <future>
 
 namespace rt {
 
@@ -17,10 +18,29 @@ const double kIntersectCost = 1.0;  // bvh.rs:15
 const double kTraversalCost = 2.0;  // bvh.rs:18
 const size_t kMaxLeafSize = 8;      // bvh.rs:23
 
+// Subtrees are independent (disjoint ranges of `items`, sorted in place), so the top levels hand their left
+// child to another thread; each task builds into its own node array and the parent splices the arrays back in
+// the order a sequential build would have produced (self, left subtree, right subtree).
+constexpr size_t kParallelMin = 8192;   // smallest range worth a task
+constexpr uint32_t kParallelDepth = 4;  // levels that fork: at most 2^4 tasks
+
+int32_t splice(Bvh& dst, const Bvh& src) {
+    const int32_t base = (int32_t)dst.nodes.size();
+    for (BvhNode n : src.nodes) {
+        if (!n.is_leaf()) n.left += base, n.right += base;
+        dst.nodes.push_back(n);
+    }
+    dst.max_depth = std::max(dst.max_depth, src.max_depth);
+    dst.max_leaf_size = std::max(dst.max_leaf_size, src.max_leaf_size);
+    dst.n_leaves += src.n_leaves;
+    return base;
+}
+
 struct Builder {
-    std::vector<Item> items;
+    std::vector<Item>& items;
     std::vector<Aabb> merge_left, merge_right;  // scratch for the sweep
     Bvh* out = nullptr;
+    explicit Builder(std::vector<Item>& it, Bvh* o) : items(it), out(o) {}
 
     int32_t make_leaf(size_t first, size_t count, uint32_t depth) {
         BvhNode n;
@@ -84,8 +104,22 @@ struct Builder {
         if (split == 0) return make_leaf(first, n, depth);
         int32_t self = (int32_t)out->nodes.size();
         out->nodes.emplace_back();
-        int32_t l = build(first, split, depth + 1);
-        int32_t r = build(first + split, n - split, depth + 1);
+        int32_t l, r;
+        if (depth <= kParallelDepth && split >= kParallelMin && n - split >= kParallelMin) {
+            Bvh left_tree, right_tree;
+            auto left_job = std::async(std::launch::async, [&]() {
+                Builder b(items, &left_tree);
+                b.build(first, split, depth + 1);
+            });
+            Builder b(items, &right_tree);
+            b.build(first + split, n - split, depth + 1);
+            left_job.get();
+            l = splice(*out, left_tree);
+            r = splice(*out, right_tree);
+        } else {
+            l = build(first, split, depth + 1);
+            r = build(first + split, n - split, depth + 1);
+        }
         BvhNode& node = out->nodes[self];
         node.left = l;
         node.right = r;
@@ -119,17 +153,16 @@ Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
 
 void build_bvh(const rt_scene_desc& d, Bvh& out) {
     out = Bvh{};
-    Builder b;
-    b.out = &out;
-    b.items.resize(d.n_surfaces);
-    for (size_t i = 0; i < d.n_surfaces; ++i) b.items[i] = {surface_bounds(d, d.surfaces[i]), (int32_t)i};
+    std::vector<Item> items(d.n_surfaces);
+    for (size_t i = 0; i < d.n_surfaces; ++i) items[i] = {surface_bounds(d, d.surfaces[i]), (int32_t)i};
+    Builder b(items, &out);
     out.nodes.reserve(d.n_surfaces / 2 + 16);
     if (d.use_bvh)
         b.build(0, d.n_surfaces, 1);
     else
         b.make_leaf(0, d.n_surfaces, 1);
     out.order.resize(d.n_surfaces);
-    for (size_t i = 0; i < d.n_surfaces; ++i) out.order[i] = b.items[i].id;
+    for (size_t i = 0; i < d.n_surfaces; ++i) out.order[i] = items[i].id;
 }
 
 }  // namespace rt

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <future>
 
 #include "bvh_build.h"
 
@@ -29,10 +30,48 @@ double area(const Aabb& b) {
 
 constexpr uint32_t kBalancedFromDepth = 32;  // root = 1; 32 + log2(2^24 primitives) = 56 = the kernels' stack
 
+constexpr size_t kParallelMin = 8192;   // as in bvh_build.cpp: the top levels fork their left child
+constexpr uint32_t kParallelDepth = 4;
+
+int32_t splice(Bvh& dst, const Bvh& src) {
+    const int32_t base = (int32_t)dst.nodes.size();
+    for (BvhNode n : src.nodes) {
+        if (!n.is_leaf()) n.left += base, n.right += base;
+        dst.nodes.push_back(n);
+    }
+    dst.max_depth = std::max(dst.max_depth, src.max_depth);
+    dst.max_leaf_size = std::max(dst.max_leaf_size, src.max_leaf_size);
+    dst.n_leaves += src.n_leaves;
+    return base;
+}
+
 struct RBuilder {
-    std::vector<Item> items;
+    std::vector<Item>& items;
     Bvh* out;
     uint32_t max_leaf;
+    RBuilder(std::vector<Item>& it, Bvh* o, uint32_t ml) : items(it), out(o), max_leaf(ml) {}
+
+    // both subtrees of the node `self` (already pushed); [first, mid) and [mid, first + n)
+    void children(int32_t self, const Aabb& box, size_t first, size_t mid, size_t n, uint32_t depth) {
+        int32_t l, r;
+        if (depth <= kParallelDepth && mid - first >= kParallelMin && first + n - mid >= kParallelMin) {
+            Bvh left_tree, right_tree;
+            auto left_job = std::async(std::launch::async, [&]() {
+                RBuilder b(items, &left_tree, max_leaf);
+                b.build(first, mid - first, depth + 1);
+            });
+            RBuilder b(items, &right_tree, max_leaf);
+            b.build(mid, first + n - mid, depth + 1);
+            left_job.get();
+            l = splice(*out, left_tree);
+            r = splice(*out, right_tree);
+        } else {
+            l = build(first, mid - first, depth + 1);
+            r = build(mid, first + n - mid, depth + 1);
+        }
+        BvhNode& node = out->nodes[self];
+        node.left = l, node.right = r, node.box = box;
+    }
 
     int32_t leaf(size_t first, size_t n, const Aabb& box, uint32_t depth) {
         BvhNode node;
@@ -65,10 +104,7 @@ struct RBuilder {
                              [axis](const Item& a, const Item& b) { return a.c.get(axis) < b.c.get(axis); });
             const int32_t self = (int32_t)out->nodes.size();
             out->nodes.emplace_back();
-            const int32_t l = build(first, mid - first, depth + 1);
-            const int32_t r = build(mid, first + n - mid, depth + 1);
-            BvhNode& node = out->nodes[self];
-            node.left = l, node.right = r, node.box = box;
+            children(self, box, first, mid, n, depth);
             return self;
         }
 
@@ -122,10 +158,7 @@ struct RBuilder {
         }
         const int32_t self = (int32_t)out->nodes.size();
         out->nodes.emplace_back();
-        const int32_t l = build(first, mid - first, depth + 1);
-        const int32_t r = build(mid, first + n - mid, depth + 1);
-        BvhNode& node = out->nodes[self];
-        node.left = l, node.right = r, node.box = box;
+        children(self, box, first, mid, n, depth);
         return self;
     }
 };
@@ -135,20 +168,18 @@ struct RBuilder {
 void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out) {
     out = Bvh{};
     if (getenv("RT_CT")) kTraversalCost = atof(getenv("RT_CT"));
-    RBuilder b;
-    b.out = &out;
-    b.max_leaf = std::max(1u, max_leaf);
-    b.items.resize(ids.size());
+    std::vector<Item> items(ids.size());
+    RBuilder b(items, &out, std::max(1u, max_leaf));
     for (size_t i = 0; i < ids.size(); ++i) {
         Aabb box = surface_bounds(d, d.surfaces[ids[i]]);
         // a negative-radius sphere has an inverted box in the reference; the render tree needs a real one
         Aabb fixed{vmin(box.lo, box.hi), vmax(box.lo, box.hi)};
-        b.items[i] = {fixed, 0.5 * (fixed.lo + fixed.hi), ids[i]};
+        items[i] = {fixed, 0.5 * (fixed.lo + fixed.hi), ids[i]};
     }
     out.nodes.reserve(ids.size());
     if (!ids.empty()) b.build(0, ids.size(), 1);
     out.order.resize(ids.size());
-    for (size_t i = 0; i < ids.size(); ++i) out.order[i] = b.items[i].id;
+    for (size_t i = 0; i < ids.size(); ++i) out.order[i] = items[i].id;
 }
 
 }  // namespace rt
