@@ -104,3 +104,28 @@ def test_repeated_renders_of_different_sizes_share_one_scene(ra):
     assert big.shape == (200, 300, 3) and np.isfinite(big).all()
     assert np.allclose(a1, a2, rtol=1e-5, atol=1e-6)
     s.close()
+
+
+def test_baseline_config_c1_in_full_on_both_sides(ra, ref):
+    """BASELINE.json configs[0] / SURVEY §8 C1: cornell.yaml 400x400 at 100 spp, the one configuration small
+    enough to run in full through the oracle (~5 s on 16 host threads) and the GPU."""
+    w = h = 400
+    s = ra.Scene(ra.load_scene(scene_path("cornell"), 1.0), 0)
+    o = ref.RefScene.from_yaml(scene_path("cornell"), 1.0)
+    for sampler in (0, 1):
+        want, _ = o.render(w, h, 10, threads=16, sampler=sampler)
+        img, st = s.render(w, h, 10, sampler=sampler)
+        assert st.samples == 16_000_000
+        _check_image(img, want, 100, f"C1 sampler {sampler}")
+    s.close()
+
+
+def test_4k_frame_and_eight_strata_slices(ra):
+    """SURVEY §8 C4 geometry (cornell_lucy.yaml 3840x2160, 8 GPUs) at reduced spp: the frame renders, stays
+    finite, and the eight ranks' strata slices add up to the single-GPU frame."""
+    s = ra.Scene(ra.load_scene(scene_path("cornell_lucy"), 3840 / 2160), 0)
+    full, st = s.render(3840, 2160, 4)
+    assert st.samples == 3840 * 2160 * 16 and np.isfinite(full).all() and full.min() >= 0
+    parts = sum(s.render(3840, 2160, 4, stratum_begin=g, stratum_step=8)[0].astype(np.float64) for g in range(8))
+    assert np.allclose(parts, full, rtol=1e-5, atol=1e-5)
+    s.close()
