@@ -102,6 +102,13 @@ typedef struct rt_scene_desc {
 /* Parses the scene YAML, loads OBJ(.gz) meshes, bakes transforms, builds the camera for
  * `aspect_ratio`.  *out is owned by the library; release with rt_scene_desc_free. */
 int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_scene_desc** out);
+
+/* Procedural example scenes: replaces Example::from_str + Example::scene (scene/example.rs:53-79) for
+ * "one-weekend" (example.rs:84-142; the reference's default when no --scene is given, main.rs:102-106) and
+ * "cornell" (example.rs:262-329, its rotated/translated boxes baked into quads).  The other six examples
+ * need textures, moving spheres or volumes and return an error naming that.  The reference draws
+ * one-weekend from thread_rng(); here `seed` fixes the draws.  Release *out with rt_scene_desc_free. */
+int rt_example_scene(const char* name, double aspect_ratio, uint64_t seed, int use_bvh, rt_scene_desc** out);
 void rt_scene_desc_free(rt_scene_desc* desc);
 
 /* ---- device scene: BVH build (bvh.rs:131-234) + SoA flattening + upload to HBM ---- */

@@ -73,6 +73,26 @@ class RefScene:
     def from_yaml(cls, path, aspect_ratio, use_bvh=True):
         return cls(loader_ref.load_scene(path, aspect_ratio), use_bvh)
 
+    @classmethod
+    def from_desc(cls, desc, camera_params, use_bvh=True):
+        """Oracle over the arrays of a product SceneDesc (procedural example scenes have no file to re-load).
+        `camera_params` = [vfov_deg, aspect, from xyz, towards xyz, aperture, has_focus, focus_dist]: the oracle
+        builds its own camera from them (camera.rs:43-74), so the product's camera is checked, not trusted."""
+        flat = loader_ref.FlatScene()
+        m, s, t, q = desc.materials, desc.spheres, desc.triangles, desc.quads
+        flat.materials = np.column_stack([m["kind"].astype(np.float64), m["albedo"], m["param"]]).reshape(-1, 5)
+        flat.spheres = np.column_stack([s["center"], s["radius"], s["material"].astype(np.float64)]).reshape(-1, 5)
+        flat.triangles = (np.column_stack([t["v"].reshape(len(t), 9), t["n"].reshape(len(t), 9),
+                                           t["material"].astype(np.float64)]).reshape(-1, 19)
+                          if len(t) else np.zeros((0, 19)))
+        flat.quads = (np.column_stack([q["q"], q["u"], q["v"], q["material"].astype(np.float64)]).reshape(-1, 10)
+                      if len(q) else np.zeros((0, 10)))
+        sf = desc.surfaces
+        flat.surfaces = np.column_stack([sf["type"], sf["index"]]).astype(np.int32)
+        flat.background = np.array(desc.background, dtype=np.float64)
+        flat.camera = np.array(camera_params, dtype=np.float64)
+        return cls(flat, use_bvh)
+
     def close(self):
         if getattr(self, "_h", None):
             lib().ref_scene_destroy(self._h)

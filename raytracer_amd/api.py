@@ -22,7 +22,7 @@ RT_SAMPLER_REFERENCE, RT_SAMPLER_DIRECT = 0, 1
 
 # every symbol include/rt.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "rt_load_scene", "rt_scene_desc_free", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
+    "rt_load_scene", "rt_example_scene", "rt_scene_desc_free", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_leaf_order", "rt_render_device", "rt_render", "rt_primary_hits", "rt_tonemap_rgb8",
     "rt_tonemap_rgb8_device", "rt_write_png", "rt_set_verbose", "rt_last_error", "rt_version",
 ]
@@ -113,6 +113,8 @@ def lib() -> C.CDLL:
     vp, i32, u32, u64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
     L.rt_load_scene.argtypes = [C.c_char_p, dbl, i32, C.POINTER(C.POINTER(RtSceneDesc))]
     L.rt_load_scene.restype = i32
+    L.rt_example_scene.argtypes = [C.c_char_p, dbl, C.c_uint64, i32, C.POINTER(C.POINTER(RtSceneDesc))]
+    L.rt_example_scene.restype = i32
     L.rt_scene_desc_free.argtypes = [C.POINTER(RtSceneDesc)]
     L.rt_scene_desc_free.restype = None
     L.rt_scene_create.argtypes = [C.POINTER(RtSceneDesc), i32, C.POINTER(vp)]
@@ -218,6 +220,13 @@ def load_scene(path: str, aspect_ratio: float, use_bvh: bool = True) -> SceneDes
     """scene::load_scene(path, aspect_ratio, use_bvh) — load.rs:39-160."""
     out = C.POINTER(RtSceneDesc)()
     _check(lib().rt_load_scene(os.fsencode(path), float(aspect_ratio), 1 if use_bvh else 0, C.byref(out)))
+    return SceneDesc(out)
+
+
+def example_scene(name: str, aspect_ratio: float, seed: int = 0x5EED5EED, use_bvh: bool = True) -> SceneDesc:
+    """Example::scene — scene/example.rs:69-79 ("one-weekend", "cornell")."""
+    out = C.POINTER(RtSceneDesc)()
+    _check(lib().rt_example_scene(name.encode(), float(aspect_ratio), int(seed), 1 if use_bvh else 0, C.byref(out)))
     return SceneDesc(out)
 
 

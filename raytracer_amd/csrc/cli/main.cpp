@@ -47,7 +47,8 @@ void help() {
         "      --aspect-ratio <ASPECT_RATIO>  Output image aspect ratio [default: 1.5]\n"
         "      --seed <SEED>                  Seed to use for RNG\n"
         "      --scene <SCENE>                A scene file to load from configuration\n"
-        "      --example <EXAMPLE>            (not supported: procedural book scenes are outside this build)\n"
+        "      --example <EXAMPLE>            An example scene from the book, generated at random: one-weekend\n"
+        "                                     (default without --scene) or cornell; drawn from --seed\n"
         "      --no-progress                  Accepted for compatibility\n"
         "      --no-bvh                       Disables the use of the bvh acceleration structure\n"
         "      --gpus <N>                     Shard the strata over N GPUs [default: 1]\n"
@@ -131,18 +132,19 @@ int main(int argc, char** argv) {
     const size_t height = o.has_height ? o.height : (size_t)((double)width / o.aspect_ratio);
     const double aspect = o.has_height ? (double)width / (double)o.height : o.aspect_ratio;
     const uint32_t max_depth = 40;  // main.rs:118
-    if (!o.has_scene) {
-        std::fprintf(stderr,
-                     "Error: --scene is required: the procedural --example scenes (default `one-weekend`) are outside "
-                     "this build's scope (SURVEY.md §8f)\n");
-        return 1;
-    }
     if (o.gpus < 1) o.gpus = 1;
     const auto start = std::chrono::steady_clock::now();
     rt_set_verbose(1);
 
     rt_scene_desc* desc = nullptr;
-    if (rt_load_scene(o.scene.c_str(), aspect, o.no_bvh ? 0 : 1, &desc)) return die("");
+    // TracerOpt::scene, main.rs:96-107: a scene file if given, else the example (default one-weekend)
+    const uint64_t scene_seed = o.has_seed ? o.seed : 0x5eed5eedull;
+    if (o.has_scene) {
+        if (rt_load_scene(o.scene.c_str(), aspect, o.no_bvh ? 0 : 1, &desc)) return die("");
+    } else if (rt_example_scene(o.has_example ? o.example.c_str() : "one-weekend", aspect, scene_seed, o.no_bvh ? 0 : 1,
+                                &desc)) {
+        return die("");
+    }
     std::vector<rt_scene*> scenes((size_t)o.gpus, nullptr);
     for (int g = 0; g < o.gpus; ++g)
         if (rt_scene_create(desc, g, &scenes[(size_t)g])) return die("create device scene");

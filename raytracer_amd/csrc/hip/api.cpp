@@ -92,7 +92,7 @@ struct rt_scene {
     std::vector<int4> loose;
     std::vector<uint4> loose_rec;
     std::vector<int32_t> render_ids;  // surfaces that live in the render tree
-    std::vector<double> sphere_gate;
+    std::vector<double> sphere_gate, quad_gate;
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
     std::vector<Node64> nodes64;
@@ -239,8 +239,7 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s) {
             BvhNode leaf;
             leaf.box = Aabb::empty();
             for (int32_t id : tree_ids) {
-                Aabb b = surface_bounds(d, d.surfaces[id]);
-                leaf.box = leaf.box.merge(Aabb{vmin(b.lo, b.hi), vmax(b.lo, b.hi)});
+                leaf.box = leaf.box.merge(true_bounds(d, d.surfaces[id]));
             }
             leaf.first = 0, leaf.count = (int32_t)tree_ids.size();
             rb.nodes.push_back(leaf);
@@ -356,22 +355,22 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         s.spheres[4 * i + 3] = d.spheres[i].radius;
         s.sphere_mat[i] = d.spheres[i].material;
     }
-    // gate of a sphere = box of the reference tree's leaf that holds it (see leaf_gate_hit in device_rt.h)
+    // gate of a sphere / quad = box of the reference tree's leaf that holds it (see leaf_gate_hit in device_rt.h)
     s.sphere_gate.assign(6 * std::max<size_t>(d.n_spheres, 1), 0.0);
+    s.quad_gate.assign(6 * std::max<size_t>(d.n_quads, 1), 0.0);
     for (const BvhNode& n : s.bvh.nodes) {
         if (!n.is_leaf()) continue;
         for (int32_t k = n.first; k < n.first + n.count; ++k) {
             const rt_surface_ref& ref = d.surfaces[s.bvh.order[k]];
-            if (ref.type != RT_SURF_SPHERE) continue;
-            for (int a = 0; a < 3; ++a)
-                s.sphere_gate[6 * ref.index + a] = n.box.lo.get(a), s.sphere_gate[6 * ref.index + 3 + a] = n.box.hi.get(a);
-            // a leaf box that encloses the sphere is crossed by every ray that hits the sphere: no test needed
-            const rt_sphere& sp = d.spheres[ref.index];
+            if (ref.type == RT_SURF_TRIANGLE) continue;  // Triangle::bounding_box is exact
+            double* gate = ref.type == RT_SURF_SPHERE ? &s.sphere_gate[6 * ref.index] : &s.quad_gate[6 * ref.index];
+            for (int a = 0; a < 3; ++a) gate[a] = n.box.lo.get(a), gate[3 + a] = n.box.hi.get(a);
+            // a leaf box that encloses the surface is crossed by every ray that hits the surface: no test needed
+            const Aabb tb = true_bounds(d, ref);
             bool encloses = true;
             for (int a = 0; a < 3; ++a)
-                encloses = encloses && n.box.lo.get(a) <= sp.center[a] - std::fabs(sp.radius) &&
-                           sp.center[a] + std::fabs(sp.radius) <= n.box.hi.get(a);
-            if (encloses) s.sphere_gate[6 * ref.index] = -INFINITY;
+                encloses = encloses && n.box.lo.get(a) <= tb.lo.get(a) && tb.hi.get(a) <= n.box.hi.get(a);
+            if (encloses) gate[0] = -INFINITY;
         }
     }
     s.quads.assign(16 * d.n_quads, 0.0);
@@ -396,8 +395,11 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         if (l.x == RT_SURF_SPHERE) {
             std::memcpy(rec + 1, &s.spheres[4 * l.y], 4 * sizeof(double));
             std::memcpy(rec + 3, &s.sphere_gate[6 * l.y], 6 * sizeof(double));
+        } else {
+            double* data = reinterpret_cast<double*>(rec + 1);
+            std::memcpy(data, &s.quads[16 * l.y], 13 * sizeof(double));
+            std::memcpy(data + 13, &s.quad_gate[6 * l.y], 6 * sizeof(double));
         }
-        else std::memcpy(rec + 1, &s.quads[16 * l.y], 13 * sizeof(double));
     }
     s.materials.resize(d.n_materials);
     s.mat_kind.resize(d.n_materials);
@@ -491,6 +493,18 @@ int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_sc
     }
 }
 
+int rt_example_scene(const char* name, double aspect_ratio, uint64_t seed, int use_bvh, rt_scene_desc** out) {
+    if (!name || !out) return set_error("rt_example_scene: null argument");
+    try {
+        auto hs = std::make_unique<HostScene>();
+        example_scene(name, aspect_ratio, seed, use_bvh != 0, *hs);
+        *out = &hs.release()->desc;
+        return 0;
+    } catch (const std::exception& e) {
+        return set_error(e.what());
+    }
+}
+
 void rt_scene_desc_free(rt_scene_desc* desc) {
     if (desc) delete reinterpret_cast<HostScene*>(desc);
 }
@@ -539,6 +553,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.loose_rec = upload(*s, s->loose_rec);
         s->dev.spheres = upload(*s, s->spheres);
         s->dev.sphere_gate = upload(*s, s->sphere_gate);
+        s->dev.quad_gate = upload(*s, s->quad_gate);
         s->dev.quads = upload(*s, s->quads);
         s->dev.sphere_mat = upload(*s, s->sphere_mat);
         s->dev.quad_mat = upload(*s, s->quad_mat);

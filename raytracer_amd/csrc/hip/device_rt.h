@@ -202,10 +202,11 @@ __device__ __forceinline__ double sphere_root(const double* sp, D3 o, D3 d, doub
     return -1.0;
 }
 
-// Aabb::hit (trace.rs:131-149) on the box of the reference tree's leaf that holds a negative-radius sphere.
-// Sphere::bounding_box gives such a sphere an inverted box, which adds nothing to its leaf's box: the
-// reference only ever tests it for rays that hit the rest of the leaf (BVHLeafNode::hit, bvh.rs:300-303), and
-// never when it is alone in a leaf.  gate = lo.xyz hi.xyz.
+// Aabb::hit (trace.rs:131-149) on the box of the reference tree's leaf that holds a surface whose own
+// reference bounding box does not cover it: a negative-radius sphere (Sphere::bounding_box inverts) or a
+// parallelogram whose sides share an axis (Quad::bounding_box spans only q and q+u+v).  Such a box adds too
+// little to its leaf's box, and the reference tests the surface only for rays that hit the leaf's box
+// (BVHLeafNode::hit, bvh.rs:300-303) — never, for a negative sphere alone in a leaf.  gate = lo.xyz hi.xyz.
 __device__ __attribute__((noinline)) bool leaf_gate_hit(const double* gate, D3 o, D3 d, double t_min) {
     const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
     double t_max = __builtin_inf();
@@ -243,6 +244,13 @@ __device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double 
     double alpha = dot(p, d3(q + 7));
     double beta = dot(p, d3(q + 10));
     if (!(0.0 <= alpha && alpha < 1.0 && 0.0 <= beta && beta < 1.0)) return -1.0;
+    return t;
+}
+
+__device__ __forceinline__ double quad_root_gated(const double* q, const double* gate, D3 o, D3 d, double tmin,
+                                                  double tmax) {
+    double t = quad_root(q, o, d, tmin, tmax);
+    if (t >= 0.0 && gate[0] != -__builtin_inf() && !leaf_gate_hit(gate, o, d, tmin)) t = -1.0;
     return t;
 }
 
@@ -291,7 +299,7 @@ __device__ __forceinline__ void loose_hits(const uint4* recs, uint32_t n_loose, 
             t = sphere_root_gated(loose_data(recs, i), loose_data(recs, i) + 4, ray.o, dd, (double)tmin, (double)best.h.t);
         } else {
             if (STATS) st.quads++;
-            t = quad_root(loose_data(recs, i), ray.o, dd, (double)tmin, (double)best.h.t);
+            t = quad_root_gated(loose_data(recs, i), loose_data(recs, i) + 13, ray.o, dd, (double)tmin, (double)best.h.t);
         }
         const float tf = (float)t;
         if (tf >= tmin && (tf < best.h.t || (tf == best.h.t && (int)m.z > best.rank))) {
@@ -402,7 +410,8 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
         t = (float)t64;
     } else {
         if (STATS) st.quads++;
-        t64 = quad_root(sc.quads + 16 * (meta >> kMetaIndexShift), ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+        t64 = quad_root_gated(sc.quads + 16 * (meta >> kMetaIndexShift), sc.quad_gate + 6 * (meta >> kMetaIndexShift), ray.o,
+                              d3(ray.d), (double)tmin, (double)best.h.t);
         t = (float)t64;
     }
     if (t >= tmin && t <= best.h.t) {

@@ -13,7 +13,7 @@ constexpr uint32_t kMetaLast = 4u;
 constexpr int kMetaIndexShift = 3;
 constexpr int kNoChild = 0x7fffffff;  // "empty" child of the synthetic root when the tree is one leaf
 constexpr uint32_t kMaxLoose = 16;    // at most this many spheres+quads are tested by every ray ("loose")
-constexpr uint32_t kLooseRecQuads = 8;  // uint4 per loose record: {type, index, rank, material} + 14 doubles
+constexpr uint32_t kLooseRecQuads = 11;  // uint4 per loose record: {type, index, rank, material} + 20 doubles
 
 // f64 records for the exact-parity kernel (array of structs; speed is irrelevant there).
 struct Node64 {
@@ -45,7 +45,7 @@ struct DevScene {
     const float4* tri_shade;    // 3 per leaf slot: vertex normals n0 n1 n2; [0].w = material id bits
     const int4* loose;          // spheres/quads tested by every ray before traversal: type, index, rank, surface id
     const uint4* loose_rec;     // the same, self-contained (kLooseRecQuads uint4 each): {type, index, rank, material},
-                                //   then the sphere's c.xyz r + gate lo hi or the quad's normal d q A B as doubles; the
+                                //   then the sphere's c.xyz r + gate lo hi or the quad's normal d q A B + gate lo hi as doubles; the
                                 //   persistent kernels stage these in LDS
     uint32_t n_loose;
     uint32_t has_tree;          // 0: no surface lives in the render tree (all are loose)
@@ -55,6 +55,8 @@ struct DevScene {
                                 //   negative radii only (their inverted bounding box adds nothing to the leaf's
                                 //   box, so the reference reaches them only through the leaf's other members)
     const double* quads;        // 16 per quad: normal(3) d q(3) A=v×w (3) B=w×u (3) pad(3)
+    const double* quad_gate;    // 6 per quad, like sphere_gate: Quad::bounding_box (surfaces.rs:356-359) spans only
+                                //   q and q+u+v, which is too small for a parallelogram whose sides share an axis
     const int32_t* sphere_mat;  // material id per sphere
     const int32_t* quad_mat;    // material id per quad
     const float4* materials;    // 1 per material: albedo.xyz, w = fuzz | refractive index

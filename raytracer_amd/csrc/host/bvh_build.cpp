@@ -1,6 +1,7 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <cmath>
 #include <future>
 
 namespace rt {
@@ -148,6 +149,23 @@ Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
             V3 a = v3(q.q), b = a + v3(q.u) + v3(q.v);
             return Aabb{vmin(a, b), vmax(a, b)}.pad(0.0001);
         }
+    }
+}
+
+Aabb true_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
+    switch (s.type) {
+        case RT_SURF_SPHERE: {
+            const rt_sphere& sp = d.spheres[s.index];
+            const double r = std::fabs(sp.radius);
+            return {v3(sp.center) - V3{r, r, r}, v3(sp.center) + V3{r, r, r}};
+        }
+        case RT_SURF_QUAD: {
+            const rt_quad& q = d.quads[s.index];
+            const V3 a = v3(q.q), u = v3(q.u), v = v3(q.v);
+            return {vmin(vmin(a, a + u), vmin(a + v, a + u + v)), vmax(vmax(a, a + u), vmax(a + v, a + u + v))};
+        }
+        default:
+            return surface_bounds(d, s);
     }
 }
 

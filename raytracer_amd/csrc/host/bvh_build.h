@@ -29,6 +29,10 @@ struct Bvh {
 // Bounding box of one surface: surfaces.rs:57-69 (sphere), 281-291 (triangle), 356-359 (quad).
 Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s);
 
+// What the surface really occupies (the reference's boxes are inverted for negative radii and too small for
+// parallelograms whose sides share an axis): the render tree is built over these.
+Aabb true_bounds(const rt_scene_desc& d, const rt_surface_ref& s);
+
 // use_bvh == false gives the single-leaf tree of Bvh::new_leaf (bvh.rs:63-68).
 void build_bvh(const rt_scene_desc& d, Bvh& out);
 

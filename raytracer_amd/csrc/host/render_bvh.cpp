@@ -171,9 +171,9 @@ void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, u
     std::vector<Item> items(ids.size());
     RBuilder b(items, &out, std::max(1u, max_leaf));
     for (size_t i = 0; i < ids.size(); ++i) {
-        Aabb box = surface_bounds(d, d.surfaces[ids[i]]);
-        // a negative-radius sphere has an inverted box in the reference; the render tree needs a real one
-        Aabb fixed{vmin(box.lo, box.hi), vmax(box.lo, box.hi)};
+        // the reference's box is inverted for a negative radius and too small for some quads: real bounds here,
+        // padded like the reference pads its (possibly flat) quad boxes
+        const Aabb fixed = true_bounds(d, d.surfaces[ids[i]]).pad(d.surfaces[ids[i]].type == RT_SURF_QUAD ? 0.0001 : 0.0);
         items[i] = {fixed, 0.5 * (fixed.lo + fixed.hi), ids[i]};
     }
     out.nodes.reserve(ids.size());

@@ -23,6 +23,9 @@ struct HostScene {
 // load.rs:39-160.  Throws std::runtime_error with an anyhow-like "context: cause" message.
 void load_scene_file(const std::string& yaml_path, double aspect_ratio, bool use_bvh, HostScene& out);
 
+// scene/example.rs:69-79 (one-weekend, cornell).  Throws std::runtime_error for the others.
+void example_scene(const std::string& name, double aspect_ratio, uint64_t seed, bool use_bvh, HostScene& out);
+
 // camera.rs:43-74
 rt_camera build_camera(double vfov_degrees, double aspect_ratio, V3 from, V3 towards, V3 vup, double aperture,
                        bool has_focus, double focus_dist);

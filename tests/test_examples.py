@@ -1,0 +1,99 @@
+"""Procedural example scenes (scene/example.rs:69-79): `one-weekend` — the reference CLI's default scene — and
+`cornell`.  The reference draws one-weekend from thread_rng(), so there is no fixture to compare the scene's
+content with; what is pinned is the generator's structure (counts, fixed spheres, camera) and, on the GPU,
+render parity with the oracle over the very arrays the generator produced."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CAMERAS = {  # [vfov, aspect, from, towards, aperture, has_focus, focus] as in example.rs:85-90 / 263-266
+    "one-weekend": lambda a: [20.0, a, 13, 2, 3, 0, 0, 0, 0.1, 1.0, 10.0],
+    "cornell": lambda a: [40.0, a, 278, 278, -800, 278, 278, 0, 0.0, 0.0, 0.0],
+}
+
+
+def test_one_weekend_structure(ra):
+    d = ra.example_scene("one-weekend", 1.5, seed=3)
+    s, m = d.spheres, d.materials
+    assert 400 < len(s) <= 488 and len(m) == len(s)           # 22 x 22 grid minus the cells near (4, 0.2, 0)
+    assert s["center"][0].tolist() == [0, -1000, 0] and s["radius"][0] == 1000
+    assert s["center"][-3:].tolist() == [[-4, 1, 0], [0, 1, 0], [4, 1, 0]] and np.all(s["radius"][-3:] == 1.0)
+    assert m["kind"][-3:].tolist() == [0, 2, 1] and m["param"][-2] == 1.5 and m["param"][-1] == 0.0
+    small = s[1:-3]
+    assert np.all(small["radius"] == 0.2) and np.all(small["center"][:, 1] == 0.2)
+    assert np.all(np.linalg.norm(small["center"] - [4.0, 0.2, 0.0], axis=1) > 0.9)
+    kinds = m["kind"][1:-3]
+    frac = [(kinds == k).mean() for k in (0, 1, 2)]            # 80 % diffuse, 15 % metal, 5 % glass
+    assert abs(frac[0] - 0.8) < 0.08 and abs(frac[1] - 0.15) < 0.06 and abs(frac[2] - 0.05) < 0.04
+    metal = m[1:-3][kinds == 1]
+    assert np.all((metal["albedo"] >= 0.5) & (metal["albedo"] < 1.0)) and np.all((metal["param"] >= 0) & (metal["param"] < 0.5))
+    assert np.array_equal(d.background, [0.7, 0.8, 1.0]) and d.camera.lens_radius == 0.05
+    # the seed fixes the draws
+    again = ra.example_scene("one-weekend", 1.5, seed=3)
+    other = ra.example_scene("one-weekend", 1.5, seed=4)
+    assert np.array_equal(again.spheres["center"], s["center"]) and not np.array_equal(other.spheres["center"][:50], s["center"][:50])
+
+
+def test_cornell_structure(ra):
+    d = ra.example_scene("cornell", 1.0)
+    q = d.quads
+    assert len(q) == 6 + 12 and len(d.spheres) == 0 and np.array_equal(d.background, [0, 0, 0])
+    assert d.materials["kind"].tolist() == [0, 0, 0, 3] and d.materials["albedo"][3].tolist() == [15, 15, 15]
+    # tall box: 165 x 333 x 165 rotated 15 degrees about its centre, moved by (265, 0, 295)
+    pts = np.concatenate([q["q"][6:12], q["q"][6:12] + q["u"][6:12], q["q"][6:12] + q["v"][6:12],
+                          q["q"][6:12] + q["u"][6:12] + q["v"][6:12]])
+    assert np.allclose(pts[:, 1].min(), 0.001) and np.allclose(pts[:, 1].max(), 333.0)
+    assert np.allclose(pts[:, [0, 2]].mean(0), [265 + 82.5, 295 + 82.5])
+    edges = np.linalg.norm(q["u"][6:12], axis=1)
+    assert np.allclose(np.sort(edges), [165] * 6)
+    c, s_ = np.cos(np.radians(15)), np.sin(np.radians(15))
+    assert np.allclose(np.abs(q["u"][6]), [165 * c, 0, 165 * s_])  # the front face's dx after the turn
+
+
+def test_examples_camera_matches_oracle_and_unsupported_names_are_refused(ra, ref):
+    for name, aspect in (("one-weekend", 1.5), ("cornell", 1.0)):
+        d = ra.example_scene(name, aspect)
+        cam = ref.RefScene.from_desc(d, CAMERAS[name](aspect)).camera()
+        for k in ("origin", "lower_left", "horizontal", "vertical", "u", "v", "w"):
+            assert np.array_equal(np.array(getattr(d.camera, k)), cam[k]), (name, k)
+    for name in ("random-spheres", "two-spheres", "two-perlin", "cornell-smoke", "earth", "final-scene"):
+        with pytest.raises(ra.api.RtError, match="textures, moving spheres or volumes"):
+            ra.example_scene(name, 1.5)
+    with pytest.raises(ra.api.RtError, match="invalid value 'teapot'"):
+        ra.example_scene("teapot", 1.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,h,sn", [("one-weekend", 150, 100, 4), ("cornell", 96, 96, 5)])
+def test_example_renders_match_the_oracle(ra, ref, name, w, h, sn):
+    from test_gpu_parity import F32_ID_MISMATCH, T_REL, _check_image
+
+    d = ra.example_scene(name, w / h, seed=11)
+    scene = ra.Scene(d, 0)
+    oracle = ref.RefScene.from_desc(d, CAMERAS[name](w / h))
+    rid, rt = oracle.primary_hits(w, h, threads=16)
+    ids, t = scene.primary_hits(w, h, precision=64)
+    assert np.array_equal(ids, rid) and np.array_equal(t, rt)
+    ids32, t32 = scene.primary_hits(w, h, precision=32)
+    mism = ids32 != rid
+    assert mism.mean() <= F32_ID_MISMATCH
+    same = ~mism & (rid >= 0)
+    assert np.max(np.abs(t32[same] - rt[same]) / rt[same], initial=0.0) <= T_REL
+    for sampler in (0, 1):
+        want, _ = oracle.render(w, h, sn, threads=16, sampler=sampler)
+        for kernel in (0, 1, 2):
+            img, st = scene.render(w, h, sn, kernel=kernel, sampler=sampler)
+            _check_image(img, want, sn * sn, f"{name} kernel {kernel} sampler {sampler}")
+    scene.close()
+
+
+@pytest.mark.gpu
+def test_cli_default_scene_is_one_weekend(tmp_path):
+    out = tmp_path / "o.png"
+    r = subprocess.run([f"{ROOT}/raytracer_amd/raytracer", "--width", "120", "-n", "4", "--seed", "5", "-o", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Done in" in r.stderr and out.stat().st_size > 1000
