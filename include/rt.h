@@ -31,21 +31,44 @@ extern "C" {
 enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3 };
 enum { RT_SURF_SPHERE = 0, RT_SURF_TRIANGLE = 1, RT_SURF_QUAD = 2 };
 
-/* material.rs:16-56 (kind + SolidColor albedo; param = fuzz | refractive index) */
+/* Texture, material.rs:183-222.  Only Lambertian materials carry one other than SOLID (material.rs:23-54). */
+enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_UV_CHECKER = 2, RT_TEX_MARBLE = 3, RT_TEX_IMAGE = 4 };
+
+/* material.rs:16-56 (kind + texture; param = fuzz | refractive index) */
 typedef struct rt_material {
     int32_t kind;
-    int32_t _pad;
-    double albedo[3];
+    int32_t texture;    /* RT_TEX_* */
+    double albedo[3];   /* SolidColor; the "even" colour of the two checkers */
     double param;
+    double albedo2[3];  /* the "odd" colour of the two checkers (material.rs:229-268) */
+    double tex_scale;   /* Checker: scale (its reciprocal multiplies the point, material.rs:193-199);
+                           UVChecker: scale of (u, v); NoiseTexture: scale of z in `marbled` (material.rs:300-303) */
+    int32_t tex_index;  /* MARBLE: index into rt_scene_desc.perlin; IMAGE: index into rt_scene_desc.images */
+    int32_t _pad;
 } rt_material;
 
-/* surfaces.rs:26-41 (stationary sphere; radius may be negative, distant.yaml:31) */
+/* surfaces.rs:26-54: the centre moves linearly from `center` (ray time 0) to `center1` (time 1) when `moving`
+ * is set; radius may be negative (distant.yaml:31) */
 typedef struct rt_sphere {
     double center[3];
     double radius;
     int32_t material;
-    int32_t _pad;
+    int32_t moving;
+    double center1[3];
 } rt_sphere;
+
+/* PerlinNoise, material.rs:281-309: 256 unit vectors and three permutations of 0..255 */
+typedef struct rt_perlin {
+    double ranvec[256][3];
+    int32_t perm[3][256];
+} rt_perlin;
+
+/* Image texture, material.rs:379-424: tightly packed RGB8 rows, top row first; width == 0 is the reference's
+ * "image could not be loaded" case, which shades (0, 1, 1) */
+typedef struct rt_image {
+    const uint8_t* rgb;
+    uint32_t width, height;
+} rt_image;
 
 /* surfaces.rs:195-243: the three vertices and vertex normals a Triangle resolves through its Mesh */
 typedef struct rt_triangle {
@@ -95,6 +118,10 @@ typedef struct rt_scene_desc {
     rt_camera camera;
     int32_t use_bvh; /* 0 = one leaf holding every surface (--no-bvh, main.rs:60-65, scene/mod.rs:61-65) */
     int32_t _pad;
+    const rt_perlin* perlin; /* noise tables the MARBLE textures refer to (may be null when n_perlin == 0) */
+    size_t n_perlin;
+    const rt_image* images;  /* images the IMAGE textures refer to */
+    size_t n_images;
 } rt_scene_desc;
 
 /* ---- host-side loader: replaces scene::load_scene (load.rs:39-160) ---- */

@@ -24,6 +24,9 @@ def lib():
         L.ref_scene_create.restype = vp
         L.ref_scene_create.argtypes = [dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
                                        C.c_size_t, dp, dp, C.c_int]
+        L.ref_scene_create_ext.restype = vp
+        L.ref_scene_create_ext.argtypes = [dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
+                                           C.c_size_t, dp, dp, C.c_int, dp, dp, dp, dp, C.c_size_t, dp, dp, C.c_size_t]
         L.ref_scene_destroy.argtypes = [vp]
         L.ref_leaf_order.argtypes = [vp, dp, dp]
         L.ref_camera.argtypes = [vp, dp]
@@ -64,8 +67,20 @@ class RefScene:
         sf = np.ascontiguousarray(flat.surfaces, dtype=np.int32)
         bg, cam = _d(flat.background), _d(flat.camera)
         self.n_surfaces = len(sf)
-        self._h = lib().ref_scene_create(_p(m), len(m), _p(s), len(s), _p(t), len(t), _p(q), len(q), _p(sf), len(sf),
-                                         _p(bg), _p(cam), 1 if use_bvh else 0)
+        ext = getattr(flat, "extras", None)
+        if ext is None:
+            self._h = lib().ref_scene_create(_p(m), len(m), _p(s), len(s), _p(t), len(t), _p(q), len(q), _p(sf), len(sf),
+                                             _p(bg), _p(cam), 1 if use_bvh else 0)
+        else:
+            me, se = _d(ext["mat_ext"]), _d(ext["sphere_end"])
+            pv = _d(ext["perlin_vec"])
+            pp = np.ascontiguousarray(ext["perlin_perm"], dtype=np.int32)
+            ib = np.ascontiguousarray(ext["image_bytes"], dtype=np.uint8)
+            idm = np.ascontiguousarray(ext["image_dims"], dtype=np.int64)
+            self._keep = (me, se, pv, pp, ib, idm)
+            self._h = lib().ref_scene_create_ext(_p(m), len(m), _p(s), len(s), _p(t), len(t), _p(q), len(q), _p(sf),
+                                                 len(sf), _p(bg), _p(cam), 1 if use_bvh else 0, _p(me), _p(se), _p(pv),
+                                                 _p(pp), len(pp), _p(ib), _p(idm), len(idm))
         if not self._h:
             raise RuntimeError("ref_scene_create failed (bad surface index)")
 
@@ -91,6 +106,20 @@ class RefScene:
         flat.surfaces = np.column_stack([sf["type"], sf["index"]]).astype(np.int32)
         flat.background = np.array(desc.background, dtype=np.float64)
         flat.camera = np.array(camera_params, dtype=np.float64)
+        images = desc.images
+        offs, dims = 0, []
+        for im in images:
+            dims.append([offs, im.shape[1] if im.size else 0, im.shape[0] if im.size else 0])
+            offs += im.size
+        pl = desc.perlin
+        flat.extras = dict(
+            mat_ext=np.column_stack([m["texture"].astype(np.float64), m["albedo2"], m["tex_scale"],
+                                     m["tex_index"].astype(np.float64)]).reshape(-1, 6),
+            sphere_end=np.array(s["center1"], dtype=np.float64).reshape(-1, 3),
+            perlin_vec=np.array(pl["ranvec"], dtype=np.float64).reshape(-1, 256, 3),
+            perlin_perm=np.array(pl["perm"], dtype=np.int32).reshape(-1, 3, 256),
+            image_bytes=(np.concatenate([im.reshape(-1) for im in images]) if offs else np.zeros(1, np.uint8)),
+            image_dims=np.array(dims, dtype=np.int64).reshape(-1, 3))
         return cls(flat, use_bvh)
 
     def close(self):

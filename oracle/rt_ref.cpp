@@ -133,11 +133,12 @@ struct Interval {  // trace.rs:214-225
 
 struct Material;
 struct Hit {  // trace.rs:48-76
-    Vec3 point, normal;
-    double t;
-    bool front_face;
-    const Material* material;
-    int surface;  // oracle-only: id of the surface that produced the hit
+    Vec3 point{0, 0, 0}, normal{0, 0, 0};
+    double t = 0.0;
+    bool front_face = false;
+    const Material* material = nullptr;
+    int surface = -1;  // oracle-only: id of the surface that produced the hit
+    double u = 0.0, v = 0.0;  // Hit::with_uv, trace.rs:78-84: set by spheres only
 };
 inline Hit make_hit(const Ray& ray, double t, Vec3 outward_normal, const Material* m, int surface) {
     Hit h;
@@ -187,10 +188,92 @@ struct Aabb {  // trace.rs:93-212
 
 // ------------------------------------------------------------------ material.rs
 enum Kind { Lambertian = 0, Metal = 1, Dielectric = 2, DiffuseLight = 3 };
+enum Tex { SolidColor = 0, Checker = 1, UVChecker = 2, Marble = 3, Image = 4 };
+
+// PerlinNoise, material.rs:281-377
+struct PerlinNoise {
+    Vec3 ranvec[256];
+    int perm[3][256];
+    double noise(Vec3 p) const {  // material.rs:325-344
+        const long i = (long)std::floor(p.x), j = (long)std::floor(p.y), k = (long)std::floor(p.z);
+        Vec3 buf[8];
+        for (int ii = 0; ii < 8; ++ii) {
+            const int di = ii & 1, dj = (ii & 2) >> 1, dk = (ii & 4) >> 2;
+            buf[ii] = ranvec[perm[0][(i + di) & 255] ^ perm[1][(j + dj) & 255] ^ perm[2][(k + dk) & 255]];
+        }
+        const double u = p.x - std::floor(p.x), v = p.y - std::floor(p.y), w = p.z - std::floor(p.z);
+        // trilinear_interp, material.rs:346-368
+        const double uu = u * u * (3. - 2. * u), vv = v * v * (3. - 2. * v), ww = w * w * (3. - 2. * w);
+        double acc = 0.0;
+        for (int ii = 0; ii < 8; ++ii) {
+            const double fi = (double)(ii & 1), fj = (double)((ii & 2) >> 1), fk = (double)((ii & 4) >> 2);
+            const Vec3 weight{u - fi, v - fj, w - fk};
+            acc += (fi * uu + (1.0 - fi) * (1.0 - uu)) * (fj * vv + (1.0 - fj) * (1.0 - vv)) *
+                   (fk * ww + (1.0 - fk) * (1.0 - ww)) * dot(buf[ii], weight);
+        }
+        return acc;
+    }
+    double turb(Vec3 p) const {  // material.rs:311-323
+        double acc = 0.0, weight = 1.0;
+        Vec3 temp = p;
+        for (int d = 0; d < 7; ++d) {
+            acc += weight * noise(temp);
+            weight *= 0.5;
+            temp = temp * 2.0;
+        }
+        return std::fabs(acc);
+    }
+};
+
+struct ImageTex {  // material.rs:379-424
+    std::vector<uint8_t> buf;
+    size_t width = 0, height = 0;
+    Vec3 color_at(double u, double v) const {
+        u = std::fmin(std::fmax(u, 0.0), 1.0);
+        v = 1.0 - std::fmin(std::fmax(v, 0.0), 1.0);
+        if (buf.empty()) return {0.0, 1.0, 1.0};
+        u = std::fmin(std::fmax(u, 0.0), 1.0);
+        v = std::fmin(std::fmax(v, 0.0), 1.0);
+        const size_t i = (size_t)(u * (double)(width - 1)), j = (size_t)(v * (double)(height - 1));
+        const uint8_t* px = &buf[3 * (j * width + i)];
+        const double color_scale = 1.0 / 255.0;
+        return {color_scale * (double)px[0], color_scale * (double)px[1], color_scale * (double)px[2]};
+    }
+};
+
 struct Material {
     int kind;
-    Vec3 albedo;   // Texture::SolidColor
+    Vec3 albedo;   // Texture::SolidColor; the checkers' "even"
     double param;  // fuzz | refractive index
+    int tex = SolidColor;
+    Vec3 albedo2{0, 0, 0};  // the checkers' "odd"
+    double tex_scale = 1.0;
+    const PerlinNoise* perlin = nullptr;
+    const ImageTex* image = nullptr;
+
+    // Texture::color_at, material.rs:212-221
+    Vec3 color_at(double u, double v, Vec3 p) const {
+        switch (tex) {
+            case Checker: {  // material.rs:236-247; inv_scale = scale.recip()
+                const double inv_scale = 1.0 / tex_scale;
+                const long x = (long)std::floor(inv_scale * p.x), y = (long)std::floor(inv_scale * p.y),
+                           z = (long)std::floor(inv_scale * p.z);
+                return (x + y + z) % 2 == 0 ? albedo : albedo2;
+            }
+            case UVChecker: {  // material.rs:257-267
+                const long a = (long)std::floor(tex_scale * u), b = (long)std::floor(tex_scale * v);
+                return (a + b) % 2 == 0 ? albedo : albedo2;
+            }
+            case Marble: {  // NoiseTexture::marbled, material.rs:300-303
+                const double n = 0.5 * (1.0 + std::sin(tex_scale * p.z + 10.0 * perlin->turb(p)));
+                return {n, n, n};
+            }
+            case Image:
+                return image->color_at(u, v);
+            default:
+                return albedo;
+        }
+    }
 };
 
 inline Vec3 reflect(Vec3 v, Vec3 n) { return v - (2.0 * dot(v, n)) * n; }  // material.rs:171-173
@@ -244,11 +327,11 @@ inline bool scatter(const Material& m, const Ray& ray, const Hit& hit, Rng& rng,
         default:  // DiffuseLight, material.rs:94
             return false;
     }
-    attenuation = m.albedo;
+    attenuation = m.color_at(hit.u, hit.v, hit.point);  // Material::scatter, material.rs:59-64
     return true;
 }
-inline Vec3 emit(const Material& m) {  // material.rs:66-72
-    return m.kind == DiffuseLight ? m.albedo : Vec3{0, 0, 0};
+inline Vec3 emit(const Material& m, const Hit& hit) {  // material.rs:66-72
+    return m.kind == DiffuseLight ? m.color_at(hit.u, hit.v, hit.point) : Vec3{0, 0, 0};
 }
 
 // ------------------------------------------------------------------ surfaces.rs
@@ -272,6 +355,15 @@ struct Surface {
 
     Vec3 center(double t) const { return (1. - t) * center_start + t * center_end; }  // surfaces.rs:52-54
 
+    // get_sphere_uv, surfaces.rs:108-118 (the reference computes it at every sphere hit; only the uv textures read it)
+    void sphere_uv(Vec3 n, Hit& h) const {
+        if (material->tex != UVChecker && material->tex != Image) return;
+        const double PI = 3.14159265358979323846;
+        const double theta = std::acos(-n.y);
+        const double phi = std::atan2(-n.z, n.x) + PI;
+        h.u = phi / (2.0 * PI), h.v = theta / PI;
+    }
+
     Aabb bounding_box() const {
         switch (type) {
             case SphereT: {  // surfaces.rs:57-69
@@ -291,7 +383,7 @@ struct Surface {
 
     bool hit(const Ray& ray, Interval iv, Hit& out, Counters& c) const {
         switch (type) {
-            case SphereT: {  // surfaces.rs:73-106 (the unused sphere uv, :108-118, is not computed)
+            case SphereT: {  // surfaces.rs:73-106; the sphere uv (:108-118) only where a texture reads it
                 c.sphere_tests++;
                 Vec3 cen = center(ray.time);
                 Vec3 oc = ray.origin - cen;
@@ -305,12 +397,14 @@ struct Surface {
                     if (iv.contains(temp)) {
                         Vec3 outward = (ray.at(temp) - cen) / radius;
                         out = make_hit(ray, temp, outward, material, id);
+                        sphere_uv(outward, out);
                         return true;
                     }
                     temp = (-half_b + root) / a;
                     if (iv.contains(temp)) {
                         Vec3 outward = (ray.at(temp) - cen) / radius;
                         out = make_hit(ray, temp, outward, material, id);
+                        sphere_uv(outward, out);
                         return true;
                     }
                 }
@@ -504,6 +598,8 @@ struct Camera {
 // ------------------------------------------------------------------ scene/mod.rs
 struct Scene {
     std::vector<Material> materials;
+    std::vector<PerlinNoise> perlin;
+    std::vector<ImageTex> images;
     std::unique_ptr<BVHNode> root;
     Vec3 background;
     Camera camera;
@@ -519,7 +615,7 @@ struct Scene {
             Hit hit;
             c.segments++;
             if (root->hit(ray, interval, hit, c)) {
-                Vec3 emitted = emit(*hit.material);
+                Vec3 emitted = emit(*hit.material, hit);
                 Vec3 att;
                 Ray scattered;
                 if (scatter(*hit.material, ray, hit, rng, att, scattered, sampler)) {
@@ -563,15 +659,47 @@ extern "C" {
 //   quads      n x 10: q u v material          (normal, d, w derived here per Quad::new, surfaces.rs:313-327)
 //   surfaces   n x 2 int32: type index         (load order, load.rs:57-158)
 //   camera     11    : fov aspect from(3) towards(3) aperture has_focus focus_distance
-void* ref_scene_create(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,
-                       const double* triangles, size_t n_tri, const double* quads, size_t n_quad,
-                       const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
-                       int use_bvh) {
+// Optional extras (null = none), for the example scenes' textures and moving spheres:
+//   mat_ext     n_mat x 6 : texture r2 g2 b2 tex_scale tex_index
+//   sphere_end  n_sph x 3 : centre at ray time 1 (Sphere::moving, surfaces.rs:43-50)
+//   perlin_vec  n_perlin x 256 x 3 doubles, perlin_perm n_perlin x 3 x 256 int32
+//   image_dims  n_images x 3 int64: byte offset into image_bytes, width, height
+void* ref_scene_create_ext(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,
+                           const double* triangles, size_t n_tri, const double* quads, size_t n_quad,
+                           const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
+                           int use_bvh, const double* mat_ext, const double* sphere_end, const double* perlin_vec,
+                           const int32_t* perlin_perm, size_t n_perlin, const uint8_t* image_bytes,
+                           const int64_t* image_dims, size_t n_images) {
     auto sc = std::make_unique<Scene>();
+    sc->perlin.resize(n_perlin);
+    for (size_t k = 0; k < n_perlin; ++k) {
+        for (int i = 0; i < 256; ++i) sc->perlin[k].ranvec[i] = {perlin_vec[(k * 256 + i) * 3], perlin_vec[(k * 256 + i) * 3 + 1], perlin_vec[(k * 256 + i) * 3 + 2]};
+        for (int a = 0; a < 3; ++a)
+            for (int i = 0; i < 256; ++i) sc->perlin[k].perm[a][i] = perlin_perm[(k * 3 + a) * 256 + i];
+    }
+    sc->images.resize(n_images);
+    for (size_t k = 0; k < n_images; ++k) {
+        sc->images[k].width = (size_t)image_dims[3 * k + 1], sc->images[k].height = (size_t)image_dims[3 * k + 2];
+        const size_t n = 3 * sc->images[k].width * sc->images[k].height;
+        sc->images[k].buf.assign(image_bytes + image_dims[3 * k], image_bytes + image_dims[3 * k] + n);
+    }
     sc->materials.resize(n_mat);
     for (size_t i = 0; i < n_mat; ++i) {
         const double* m = materials + 5 * i;
         sc->materials[i] = {(int)m[0], {m[1], m[2], m[3]}, m[4]};
+        if (mat_ext) {
+            const double* e = mat_ext + 6 * i;
+            Material& mm = sc->materials[i];
+            mm.tex = (int)e[0], mm.albedo2 = {e[1], e[2], e[3]}, mm.tex_scale = e[4];
+            if (mm.tex == Marble) {
+                if ((size_t)e[5] >= n_perlin) return nullptr;
+                mm.perlin = &sc->perlin[(size_t)e[5]];
+            }
+            if (mm.tex == Image) {
+                if ((size_t)e[5] >= n_images) return nullptr;
+                mm.image = &sc->images[(size_t)e[5]];
+            }
+        }
     }
     auto V = [](const double* p) { return Vec3{p[0], p[1], p[2]}; };
     std::vector<Surface> list;
@@ -585,6 +713,7 @@ void* ref_scene_create(const double* materials, size_t n_mat, const double* sphe
             const double* p = spheres + 5 * index;
             s.type = Surface::SphereT;
             s.center_start = s.center_end = V(p);  // Sphere::stationary, surfaces.rs:34-41
+            if (sphere_end) s.center_end = V(sphere_end + 3 * index);  // Sphere::moving
             s.radius = p[3];
             s.material = &sc->materials[(size_t)p[4]];
         } else if (type == 1) {
@@ -612,6 +741,14 @@ void* ref_scene_create(const double* materials, size_t n_mat, const double* sphe
     sc->background = V(background);
     sc->camera = Camera::make(camera[0], camera[1], V(camera + 2), V(camera + 5), camera[8], camera[9] != 0.0, camera[10]);
     return sc.release();
+}
+
+void* ref_scene_create(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,
+                       const double* triangles, size_t n_tri, const double* quads, size_t n_quad,
+                       const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
+                       int use_bvh) {
+    return ref_scene_create_ext(materials, n_mat, spheres, n_sph, triangles, n_tri, quads, n_quad, surfaces, n_surf,
+                                background, camera, use_bvh, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
 }
 
 void ref_scene_destroy(void* h) { delete (Scene*)h; }

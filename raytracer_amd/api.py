@@ -29,11 +29,21 @@ EXPORTED_SYMBOLS = [
 
 
 class RtMaterial(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("albedo", C.c_double * 3), ("param", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("texture", C.c_int32), ("albedo", C.c_double * 3), ("param", C.c_double),
+                ("albedo2", C.c_double * 3), ("tex_scale", C.c_double), ("tex_index", C.c_int32), ("_pad", C.c_int32)]
 
 
 class RtSphere(C.Structure):
-    _fields_ = [("center", C.c_double * 3), ("radius", C.c_double), ("material", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("center", C.c_double * 3), ("radius", C.c_double), ("material", C.c_int32), ("moving", C.c_int32),
+                ("center1", C.c_double * 3)]
+
+
+class RtPerlin(C.Structure):
+    _fields_ = [("ranvec", (C.c_double * 3) * 256), ("perm", (C.c_int32 * 256) * 3)]
+
+
+class RtImage(C.Structure):
+    _fields_ = [("rgb", C.POINTER(C.c_uint8)), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
 class RtTriangle(C.Structure):
@@ -63,6 +73,8 @@ class RtSceneDesc(C.Structure):
         ("quads", C.POINTER(RtQuad)), ("n_quads", C.c_size_t),
         ("surfaces", C.POINTER(RtSurfaceRef)), ("n_surfaces", C.c_size_t),
         ("background", C.c_double * 3), ("camera", RtCamera), ("use_bvh", C.c_int32), ("_pad", C.c_int32),
+        ("perlin", C.POINTER(RtPerlin)), ("n_perlin", C.c_size_t),
+        ("images", C.POINTER(RtImage)), ("n_images", C.c_size_t),
     ]
 
 
@@ -86,8 +98,11 @@ class RtStats(C.Structure):
 
 
 # numpy record layouts of the flat scene arrays
-MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("_pad", "<i4"), ("albedo", "<f8", 3), ("param", "<f8")])
-SPHERE_DTYPE = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("material", "<i4"), ("_pad", "<i4")])
+MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("texture", "<i4"), ("albedo", "<f8", 3), ("param", "<f8"),
+                           ("albedo2", "<f8", 3), ("tex_scale", "<f8"), ("tex_index", "<i4"), ("_pad", "<i4")])
+SPHERE_DTYPE = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("material", "<i4"), ("moving", "<i4"),
+                         ("center1", "<f8", 3)])
+PERLIN_DTYPE = np.dtype([("ranvec", "<f8", (256, 3)), ("perm", "<i4", (3, 256))])
 TRIANGLE_DTYPE = np.dtype([("v", "<f8", (3, 3)), ("n", "<f8", (3, 3)), ("material", "<i4"), ("_pad", "<i4")])
 QUAD_DTYPE = np.dtype([("q", "<f8", 3), ("u", "<f8", 3), ("v", "<f8", 3), ("normal", "<f8", 3), ("d", "<f8"),
                        ("w", "<f8", 3), ("material", "<i4"), ("_pad", "<i4")])
@@ -168,7 +183,8 @@ class SceneDesc:
     # -- construction from numpy arrays (synthetic scenes in tests)
     @classmethod
     def from_arrays(cls, materials, spheres, triangles, quads, surfaces, background, camera: RtCamera,
-                    use_bvh=True) -> "SceneDesc":
+                    use_bvh=True, perlin=None, images=()) -> "SceneDesc":
+        """`perlin`: array of PERLIN_DTYPE; `images`: sequence of uint8 arrays of shape (h, w, 3)."""
         arrs = dict(
             materials=np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE),
             spheres=np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE),
@@ -185,6 +201,16 @@ class SceneDesc:
         d.background = (C.c_double * 3)(*background)
         d.camera = camera
         d.use_bvh = 1 if use_bvh else 0
+        arrs["perlin"] = np.ascontiguousarray(perlin if perlin is not None else np.zeros(0, PERLIN_DTYPE), dtype=PERLIN_DTYPE)
+        d.perlin = C.cast(arrs["perlin"].ctypes.data, C.POINTER(RtPerlin))
+        d.n_perlin = len(arrs["perlin"])
+        arrs["image_pixels"] = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        arrs["images"] = (RtImage * max(len(images), 1))()
+        for i, im in enumerate(arrs["image_pixels"]):
+            arrs["images"][i].rgb = C.cast(im.ctypes.data, C.POINTER(C.c_uint8)) if im.size else None
+            arrs["images"][i].height, arrs["images"][i].width = (im.shape[0], im.shape[1]) if im.size else (0, 0)
+        d.images = C.cast(arrs["images"], C.POINTER(RtImage))
+        d.n_images = len(images)
         self = cls(None, arrs)
         self._struct = d
         return self
@@ -198,6 +224,17 @@ class SceneDesc:
     triangles = property(lambda s: _view(s._struct.triangles, s._struct.n_triangles, TRIANGLE_DTYPE))
     quads = property(lambda s: _view(s._struct.quads, s._struct.n_quads, QUAD_DTYPE))
     surfaces = property(lambda s: _view(s._struct.surfaces, s._struct.n_surfaces, SURFACE_DTYPE))
+    perlin = property(lambda s: _view(s._struct.perlin, s._struct.n_perlin, PERLIN_DTYPE))
+
+    @property
+    def images(self):
+        out = []
+        for i in range(self._struct.n_images):
+            im = self._struct.images[i]
+            n = 3 * im.width * im.height
+            out.append(np.ctypeslib.as_array(im.rgb, shape=(n,)).reshape(im.height, im.width, 3).copy() if n
+                       else np.zeros((0, 0, 3), np.uint8))
+        return out
     background = property(lambda s: np.array(list(s._struct.background)))
     camera = property(lambda s: s._struct.camera)
     n_surfaces = property(lambda s: int(s._struct.n_surfaces))

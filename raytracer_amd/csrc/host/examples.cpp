@@ -40,7 +40,7 @@ int add_material(HostScene& hs, int kind, V3 albedo, double param) {
 
 void add_sphere(HostScene& hs, V3 c, double r, int material) {
     rt_sphere s{};
-    s.center[0] = c.x, s.center[1] = c.y, s.center[2] = c.z;
+    s.center[0] = s.center1[0] = c.x, s.center[1] = s.center1[1] = c.y, s.center[2] = s.center1[2] = c.z;
     s.radius = r;
     s.material = material;
     hs.surfaces.push_back(rt_surface_ref{RT_SURF_SPHERE, (int32_t)hs.spheres.size()});

@@ -262,6 +262,9 @@ void HostScene::sync_desc() {
     desc.triangles = triangles.data(), desc.n_triangles = triangles.size();
     desc.quads = quads.data(), desc.n_quads = quads.size();
     desc.surfaces = surfaces.data(), desc.n_surfaces = surfaces.size();
+    desc.perlin = perlin.data(), desc.n_perlin = perlin.size();
+    for (size_t i = 0; i < images.size() && i < image_data.size(); ++i) images[i].rgb = image_data[i].data();
+    desc.images = images.data(), desc.n_images = images.size();
 }
 
 rt_quad make_quad(V3 q, V3 u, V3 v, int material) {
@@ -337,6 +340,7 @@ void load_scene_file(const std::string& yaml_path, double aspect_ratio, bool use
             rt_sphere sph{};
             sph.radius = num(field(s, "radius", "sphere"), "radius");
             v3out(sph.center, vec3(field(s, "position", "sphere"), "position"));
+            v3out(sph.center1, vec3(field(s, "position", "sphere"), "position"));  // Sphere::stationary
             sph.material = add_material(s);
             out.surfaces.push_back({RT_SURF_SPHERE, (int32_t)out.spheres.size()});
             out.spheres.push_back(sph);
