@@ -19,6 +19,7 @@ RT_SURF_SPHERE, RT_SURF_TRIANGLE, RT_SURF_QUAD = 0, 1, 2
 RT_KERNEL_PERSISTENT, RT_KERNEL_WAVEFRONT, RT_KERNEL_POOL = 0, 1, 2
 RT_DEVICE_CURRENT, RT_DEVICE_NONE = -1, -2
 RT_SAMPLER_REFERENCE, RT_SAMPLER_DIRECT = 0, 1
+RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_UV_CHECKER, RT_TEX_MARBLE, RT_TEX_IMAGE = 0, 1, 2, 3, 4
 
 # every symbol include/rt.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [

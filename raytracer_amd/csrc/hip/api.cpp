@@ -92,7 +92,12 @@ struct rt_scene {
     std::vector<int4> loose;
     std::vector<uint4> loose_rec;
     std::vector<int32_t> render_ids;  // surfaces that live in the render tree
-    std::vector<double> sphere_gate, quad_gate;
+    std::vector<double> sphere_gate, quad_gate, sphere_end, mat_scale;
+    std::vector<float4> mat_tex, perlin_vec;
+    std::vector<int32_t> perlin_perm;
+    std::vector<uint8_t> image_rgb;
+    std::vector<uint4> image_dims;
+    bool ext = false;  // any texture or moving sphere
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
     std::vector<Node64> nodes64;
@@ -132,8 +137,16 @@ void validate(const rt_scene_desc& d) {
     auto check_mat = [&](int32_t m) {
         if (m < 0 || (size_t)m >= d.n_materials) throw std::runtime_error("material index out of range");
     };
-    for (size_t i = 0; i < d.n_materials; ++i)
-        if (d.materials[i].kind < 0 || d.materials[i].kind > 3) throw std::runtime_error("unknown material kind");
+    for (size_t i = 0; i < d.n_materials; ++i) {
+        const rt_material& m = d.materials[i];
+        if (m.kind < 0 || m.kind > 3) throw std::runtime_error("unknown material kind");
+        if (m.texture < 0 || m.texture > RT_TEX_IMAGE) throw std::runtime_error("unknown texture kind");
+        if (m.texture == RT_TEX_MARBLE && (m.tex_index < 0 || (size_t)m.tex_index >= d.n_perlin))
+            throw std::runtime_error("noise table index out of range");
+        if (m.texture == RT_TEX_IMAGE && (m.tex_index < 0 || (size_t)m.tex_index >= d.n_images))
+            throw std::runtime_error("image index out of range");
+        if ((m.texture == RT_TEX_CHECKER) && !(m.tex_scale != 0.0)) throw std::runtime_error("checker scale must not be 0");
+    }
     for (size_t i = 0; i < d.n_spheres; ++i) check_mat(d.spheres[i].material);
     for (size_t i = 0; i < d.n_triangles; ++i) check_mat(d.triangles[i].material);
     for (size_t i = 0; i < d.n_quads; ++i) check_mat(d.quads[i].material);
@@ -349,10 +362,15 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     if (s.has_tree && ft.root_is_leaf) s.prims[3 * n_tree].w = uint_bits(1u | kMetaLast);
 
     s.spheres.resize(4 * d.n_spheres);
+    s.sphere_end.assign(3 * std::max<size_t>(d.n_spheres, 1), 0.0);
+    s.ext = false;
     s.sphere_mat.resize(d.n_spheres);
     for (size_t i = 0; i < d.n_spheres; ++i) {
         for (int a = 0; a < 3; ++a) s.spheres[4 * i + a] = d.spheres[i].center[a];
         s.spheres[4 * i + 3] = d.spheres[i].radius;
+        for (int a = 0; a < 3; ++a)
+            s.sphere_end[3 * i + a] = d.spheres[i].moving ? d.spheres[i].center1[a] : d.spheres[i].center[a];
+        if (d.spheres[i].moving) s.ext = true;
         s.sphere_mat[i] = d.spheres[i].material;
     }
     // gate of a sphere / quad = box of the reference tree's leaf that holds it (see leaf_gate_hit in device_rt.h)
@@ -395,6 +413,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         if (l.x == RT_SURF_SPHERE) {
             std::memcpy(rec + 1, &s.spheres[4 * l.y], 4 * sizeof(double));
             std::memcpy(rec + 3, &s.sphere_gate[6 * l.y], 6 * sizeof(double));
+            std::memcpy(rec + 6, &s.sphere_end[3 * l.y], 3 * sizeof(double));
         } else {
             double* data = reinterpret_cast<double*>(rec + 1);
             std::memcpy(data, &s.quads[16 * l.y], 13 * sizeof(double));
@@ -403,10 +422,32 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     }
     s.materials.resize(d.n_materials);
     s.mat_kind.resize(d.n_materials);
+    s.mat_tex.assign(2 * std::max<size_t>(d.n_materials, 1), float4{0, 0, 0, 0});
+    s.mat_scale.assign(2 * std::max<size_t>(d.n_materials, 1), 1.0);
     for (size_t i = 0; i < d.n_materials; ++i) {
         const rt_material& m = d.materials[i];
         s.materials[i] = {(float)m.albedo[0], (float)m.albedo[1], (float)m.albedo[2], (float)m.param};
         s.mat_kind[i] = m.kind;
+        s.mat_tex[2 * i] = {int_bits(m.texture), int_bits(m.tex_index), 0, 0};
+        s.mat_tex[2 * i + 1] = {(float)m.albedo2[0], (float)m.albedo2[1], (float)m.albedo2[2], 0};
+        s.mat_scale[2 * i] = m.tex_scale, s.mat_scale[2 * i + 1] = 1.0 / m.tex_scale;  // f64::recip, material.rs:195
+        if (m.texture != RT_TEX_SOLID) s.ext = true;
+    }
+    s.perlin_vec.assign(256 * std::max<size_t>(d.n_perlin, 1), float4{0, 0, 0, 0});
+    s.perlin_perm.assign(768 * std::max<size_t>(d.n_perlin, 1), 0);
+    for (size_t k = 0; k < d.n_perlin; ++k)
+        for (int i = 0; i < 256; ++i) {
+            const double* v = d.perlin[k].ranvec[i];
+            s.perlin_vec[256 * k + i] = {(float)v[0], (float)v[1], (float)v[2], 0};
+            for (int a = 0; a < 3; ++a) s.perlin_perm[768 * k + 256 * a + i] = d.perlin[k].perm[a][i];
+        }
+    s.image_rgb.assign(1, 0);
+    s.image_dims.assign(std::max<size_t>(d.n_images, 1), uint4{0, 0, 0, 0});
+    for (size_t k = 0; k < d.n_images; ++k) {
+        const rt_image& im = d.images[k];
+        const size_t n = (size_t)3 * im.width * im.height;
+        s.image_dims[k] = uint4{(uint32_t)s.image_rgb.size(), n ? im.width : 0u, n ? im.height : 0u, 0u};
+        if (n) s.image_rgb.insert(s.image_rgb.end(), im.rgb, im.rgb + n);
     }
     s.info.render_nodes = rb.nodes.size();
     s.info.render_depth = s.stack_depth;
@@ -554,6 +595,14 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.spheres = upload(*s, s->spheres);
         s->dev.sphere_gate = upload(*s, s->sphere_gate);
         s->dev.quad_gate = upload(*s, s->quad_gate);
+        s->dev.ext = s->ext ? 1u : 0u;
+        s->dev.sphere_end = upload(*s, s->sphere_end);
+        s->dev.mat_tex = upload(*s, s->mat_tex);
+        s->dev.mat_scale = upload(*s, s->mat_scale);
+        s->dev.perlin_vec = upload(*s, s->perlin_vec);
+        s->dev.perlin_perm = upload(*s, s->perlin_perm);
+        s->dev.image_rgb = upload(*s, s->image_rgb);
+        s->dev.image_dims = upload(*s, s->image_dims);
         s->dev.quads = upload(*s, s->quads);
         s->dev.sphere_mat = upload(*s, s->sphere_mat);
         s->dev.quad_mat = upload(*s, s->quad_mat);
@@ -603,7 +652,9 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
         if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, sizeof(DevCounters), stream));
         if (stats) HIP_CHECK(hipEventRecord(scene->ev0, stream));
         uint32_t n_launches = 1;
-        if (params->kernel == RT_KERNEL_PERSISTENT || params->kernel == RT_KERNEL_POOL) {
+        // textures and moving spheres exist in the persistent kernel only: the other organisations defer to it
+        if (params->kernel == RT_KERNEL_PERSISTENT || params->kernel == RT_KERNEL_POOL ||
+            (params->kernel == RT_KERNEL_WAVEFRONT && dev.ext)) {
             // scratch: the tile-planar accumulator, kept with the scene and grown on demand
             const size_t need = persistent_acc_bytes(rp.width, rp.height);
             if (scene->acc_bytes < need) {
@@ -616,7 +667,7 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                 scene->acc_bytes = need;
             }
             // the pooled kernel only pays when rays traverse a tree; it packs depth and pixel into one word
-            const bool pooled = params->kernel == RT_KERNEL_POOL && dev.has_tree && rp.max_depth <= 63u &&
+            const bool pooled = params->kernel == RT_KERNEL_POOL && dev.has_tree && !dev.ext && rp.max_depth <= 63u &&
                                 pool_kernel_supports(rp.width, rp.height, scene->stack_depth);
             HIP_CHECK((pooled ? launch_render_pool : launch_render_persistent)(
                 dev, rp, scene->stack_depth, scene->n_cus, scene->d_acc, d_rgb_sum, scene->d_counters,

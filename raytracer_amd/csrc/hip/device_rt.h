@@ -126,6 +126,7 @@ __device__ __forceinline__ void rng_in_unit_disk(Rng& r, float& x, float& y) {
 struct Ray {
     D3 o;  // f64 origin: exact input of the sphere/quad tests and of o + t*d
     F3 d;  // direction, NOT normalised (camera.rs:84, material.rs:110)
+    float time;  // shutter time in [0, 1) (camera.rs:80), kept along the path; read by the EXT builds only
 };
 
 struct HitRec {
@@ -160,11 +161,12 @@ __device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderPar
     float rx, ry;
     rng_in_unit_disk<DIRECT>(rng, rx, ry);  // always drawn, even for a pinhole (camera.rs:77)
     rx *= sc.cam.lens_radius, ry *= sc.cam.lens_radius;
-    (void)rng_u01(rng);  // shutter time: drawn (camera.rs:80), without effect on stationary scenes
+    const float time = rng_u01(rng);  // shutter time (camera.rs:80): without effect on stationary scenes
     F3 off = rx * f3(sc.cam.u) + ry * f3(sc.cam.v);
     Ray ray;
     ray.o = d3(sc.cam.origin) - d3(off);
     ray.d = f3(sc.cam.ll_rel) + s * f3(sc.cam.hor_px) + t * f3(sc.cam.ver_px) + off;
+    ray.time = time;
     return ray;
 }
 
@@ -184,9 +186,15 @@ __device__ __forceinline__ double sqrt64(double x) {  // x > 0
 }
 
 // Sphere, f64 (surfaces.rs:73-106).  Returns the first root inside [tmin, tmax], or -1.
-__device__ __forceinline__ double sphere_root(const double* sp, D3 o, D3 d, double tmin, double tmax) {
-    D3 oc = o - d3(sp);
-    double r = sp[3];
+// Sphere::center, surfaces.rs:52-54; the stationary builds read c0 only.
+template <bool EXT>
+__device__ __forceinline__ D3 sphere_centre(const double* c0, const double* c1, float time) {
+    if (!EXT) return d3(c0);
+    const double t = (double)time;
+    return (1.0 - t) * d3(c0) + t * d3(c1);
+}
+__device__ __forceinline__ double sphere_root(D3 centre, double r, D3 o, D3 d, double tmin, double tmax) {
+    D3 oc = o - centre;
     double a = dot(d, d);
     double half_b = dot(oc, d);
     double c = dot(oc, oc) - r * r;
@@ -225,9 +233,10 @@ __device__ __attribute__((noinline)) bool leaf_gate_hit(const double* gate, D3 o
     }
     return true;
 }
-__device__ __forceinline__ double sphere_root_gated(const double* sp, const double* gate, D3 o, D3 d, double tmin,
-                                                    double tmax) {
-    double t = sphere_root(sp, o, d, tmin, tmax);
+template <bool EXT>
+__device__ __forceinline__ double sphere_root_gated(const double* sp, const double* gate, const double* c1, float time,
+                                                    D3 o, D3 d, double tmin, double tmax) {
+    double t = sphere_root(sphere_centre<EXT>(sp, c1, time), sp[3], o, d, tmin, tmax);
     // gate[0] == -inf: the host found the leaf's box to enclose the sphere, so every hit passes
     if (t >= 0.0 && sp[3] < 0.0 && gate[0] != -__builtin_inf() && !leaf_gate_hit(gate, o, d, tmin)) t = -1.0;
     return t;
@@ -287,7 +296,7 @@ __device__ __forceinline__ void closest_reset(Closest& c) {
 __device__ __forceinline__ const double* loose_data(const uint4* recs, uint32_t i) {
     return (const double*)(recs + kLooseRecQuads * i + 1);
 }
-template <bool STATS>
+template <bool STATS, bool EXT = false>
 __device__ __forceinline__ void loose_hits(const uint4* recs, uint32_t n_loose, const Ray& ray, float tmin,
                                            Closest& best, TraceStats& st) {
     const D3 dd = d3(ray.d);
@@ -296,7 +305,8 @@ __device__ __forceinline__ void loose_hits(const uint4* recs, uint32_t n_loose, 
         double t;
         if (m.x == 0u) {
             if (STATS) st.spheres++;
-            t = sphere_root_gated(loose_data(recs, i), loose_data(recs, i) + 4, ray.o, dd, (double)tmin, (double)best.h.t);
+            t = sphere_root_gated<EXT>(loose_data(recs, i), loose_data(recs, i) + 4, loose_data(recs, i) + 10, ray.time, ray.o,
+                                       dd, (double)tmin, (double)best.h.t);
         } else {
             if (STATS) st.quads++;
             t = quad_root_gated(loose_data(recs, i), loose_data(recs, i) + 13, ray.o, dd, (double)tmin, (double)best.h.t);
@@ -378,7 +388,7 @@ __device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, f
 }
 
 // One leaf slot whose record (p0 p1 p2) is in registers.  Returns true when it was the last slot of its leaf.
-template <bool STATS>
+template <bool STATS, bool EXT = false>
 __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           float4 p0, float4 p1, float4 p2, Closest& best, TraceStats& st) {
     const uint32_t meta = __float_as_uint(p0.w);
@@ -405,8 +415,9 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
         }
     } else if (type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
         if (STATS) st.spheres++;
-        t64 = sphere_root_gated(sc.spheres + 4 * (meta >> kMetaIndexShift), sc.sphere_gate + 6 * (meta >> kMetaIndexShift),
-                                ray.o, d3(ray.d), (double)tmin, (double)best.h.t);
+        const uint32_t si = meta >> kMetaIndexShift;
+        t64 = sphere_root_gated<EXT>(sc.spheres + 4 * si, sc.sphere_gate + 6 * si, sc.sphere_end + 3 * si, ray.time, ray.o,
+                                     d3(ray.d), (double)tmin, (double)best.h.t);
         t = (float)t64;
     } else {
         if (STATS) st.quads++;
@@ -423,24 +434,24 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
     }
     return (meta & kMetaLast) != 0u;
 }
-template <bool STATS>
+template <bool STATS, bool EXT = false>
 __device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           Closest& best, TraceStats& st) {
-    return prim_test<STATS>(sc, ray, r, tmin, slot, sc.prims[3 * slot], sc.prims[3 * slot + 1], sc.prims[3 * slot + 2], best,
+    return prim_test<STATS, EXT>(sc, ray, r, tmin, slot, sc.prims[3 * slot], sc.prims[3 * slot + 1], sc.prims[3 * slot + 2], best,
                             st);
 }
 // A whole leaf.  The records of its first two slots are fetched together (render-tree leaves hold at most two
 // in all but degenerate cases; the array is padded by one slot), so a two-triangle leaf costs one memory
 // round trip, not two.
-template <bool STATS>
+template <bool STATS, bool EXT = false>
 __device__ __forceinline__ void leaf_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           Closest& best, TraceStats& st) {
     const float4 a0 = sc.prims[3 * slot + 0], a1 = sc.prims[3 * slot + 1], a2 = sc.prims[3 * slot + 2];
     const float4 b0 = sc.prims[3 * slot + 3], b1 = sc.prims[3 * slot + 4], b2 = sc.prims[3 * slot + 5];
-    if (prim_test<STATS>(sc, ray, r, tmin, slot, a0, a1, a2, best, st)) return;
-    if (prim_test<STATS>(sc, ray, r, tmin, slot + 1, b0, b1, b2, best, st)) return;
+    if (prim_test<STATS, EXT>(sc, ray, r, tmin, slot, a0, a1, a2, best, st)) return;
+    if (prim_test<STATS, EXT>(sc, ray, r, tmin, slot + 1, b0, b1, b2, best, st)) return;
     slot += 2;
-    while (!prim_step<STATS>(sc, ray, r, tmin, slot, best, st)) ++slot;
+    while (!prim_step<STATS, EXT>(sc, ray, r, tmin, slot, best, st)) ++slot;
 }
 
 // The classic while-while loop over the steps (used by wf_extend and the f32 AOV kernel).
@@ -470,8 +481,74 @@ __device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (2.0f * dot(v, n)
 // One bounce (one iteration of the loop at scene/mod.rs:103-125).  `lsum` gathers radiance in the forward
 // form  L += T*emitted; T *= albedo  (equal to resolve_color's back-to-front fold).  Returns whether the
 // path continues; `depth` follows the reference's counter including the metal re-sampling quirk (Q1).
+// ---- textures (EXT builds): Texture::color_at, material.rs:212-221
+// PerlinNoise::noise + trilinear_interp, material.rs:325-368
+__device__ __forceinline__ float perlin_noise(const float4* vec, const int32_t* perm, F3 p) {
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const float uu = u * u * (3.f - 2.f * u), vv = v * v * (3.f - 2.f * v), ww = w * w * (3.f - 2.f * w);
+    float acc = 0.f;
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+        const int di = ii & 1, dj = (ii & 2) >> 1, dk = (ii & 4) >> 2;
+        const float4 g = vec[perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)]];
+        const float fi = (float)di, fj = (float)dj, fk = (float)dk;
+        acc += (fi * uu + (1.f - fi) * (1.f - uu)) * (fj * vv + (1.f - fj) * (1.f - vv)) *
+               (fk * ww + (1.f - fk) * (1.f - ww)) * (g.x * (u - fi) + g.y * (v - fj) + g.z * (w - fk));
+    }
+    return acc;
+}
+__device__ __forceinline__ float perlin_turb(const float4* vec, const int32_t* perm, F3 p) {  // material.rs:311-323
+    float acc = 0.f, weight = 1.f;
+    for (int d = 0; d < 7; ++d) {
+        acc += weight * perlin_noise(vec, perm, p);
+        weight *= 0.5f;
+        p = 2.0f * p;
+    }
+    return fabsf(acc);
+}
+// `n_out` is the sphere's outward unit normal (get_sphere_uv, surfaces.rs:108-118); u = v = 0 for triangles and
+// quads, which never set them (trace.rs:59-84).
+__device__ __forceinline__ F3 texture_color(const DevScene& sc, int mat, F3 albedo, bool is_sphere, F3 n_out, D3 p) {
+    const float4 t0 = sc.mat_tex[2 * mat];
+    const int tex = __float_as_int(t0.x), index = __float_as_int(t0.y);
+    if (tex == 0) return albedo;
+    const F3 odd = f3(sc.mat_tex[2 * mat + 1]);
+    float u = 0.f, v = 0.f;
+    if (is_sphere && (tex == 2 || tex == 4)) {
+        const float pi = 3.14159265358979f;
+        u = (atan2f(-n_out.z, n_out.x) + pi) * (0.5f / pi);
+        v = acosf(fminf(fmaxf(-n_out.y, -1.f), 1.f)) * (1.0f / pi);
+    }
+    if (tex == 1) {  // Checker, material.rs:236-247 (the point in f64, like the reference)
+        const double inv = sc.mat_scale[2 * mat + 1];
+        const long long s = (long long)floor(inv * p.x) + (long long)floor(inv * p.y) + (long long)floor(inv * p.z);
+        return (s & 1) == 0 ? albedo : odd;
+    }
+    if (tex == 2) {  // UVChecker, material.rs:257-267
+        const float sc_ = (float)sc.mat_scale[2 * mat];
+        const int s = (int)floorf(sc_ * u) + (int)floorf(sc_ * v);
+        return (s & 1) == 0 ? albedo : odd;
+    }
+    if (tex == 3) {  // NoiseTexture::marbled, material.rs:300-303
+        const F3 pf = tof(p);
+        const float n = 0.5f * (1.0f + sinf((float)sc.mat_scale[2 * mat] * pf.z +
+                                            10.0f * perlin_turb(sc.perlin_vec + 256 * index, sc.perlin_perm + 768 * index, pf)));
+        return {n, n, n};
+    }
+    // Image::color_at, material.rs:386-424
+    const uint4 dim = sc.image_dims[index];
+    if (dim.y == 0u || dim.z == 0u) return {0.f, 1.f, 1.f};
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    v = 1.0f - fminf(fmaxf(v, 0.f), 1.f);
+    const uint32_t i = (uint32_t)(u * (float)(dim.y - 1u)), j = (uint32_t)(v * (float)(dim.z - 1u));
+    const uint8_t* px = sc.image_rgb + dim.x + 3u * (j * dim.y + i);
+    return {(float)px[0] * (1.0f / 255.0f), (float)px[1] * (1.0f / 255.0f), (float)px[2] * (1.0f / 255.0f)};
+}
+
 // `meta` is the hit slot's meta word (Closest::meta; tree hits only), `recs` the loose records as in loose_hits.
-template <bool DIRECT>
+template <bool DIRECT, bool EXT = false>
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* recs, Ray& ray, const HitRec& hit,
                                              uint32_t meta, float tmin, Rng& rng, F3& thr, F3& lsum, uint32_t& depth,
                                              uint32_t max_depth) {
@@ -512,17 +589,23 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
             c[0] = l[0], c[1] = l[1], c[2] = l[2], c[3] = l[3];
         }
         if (type == 0u) {
-            D3 nn = rcp64(c[3]) * (p - d3(c));  // signed radius: a negative one flips the normal
+            D3 centre = d3(c);
+            if (EXT) {  // the centre at this ray's time (surfaces.rs:52-54)
+                const double* c1 = hit.slot >= 0 ? sc.sphere_end + 3 * index : loose_data(recs, (uint32_t)(-2 - hit.slot)) + 10;
+                centre = sphere_centre<true>(c, c1, ray.time);
+            }
+            D3 nn = rcp64(c[3]) * (p - centre);  // signed radius: a negative one flips the normal
             n = tof(nn);
         } else {
             n = tof(d3(c));
         }
     }
+    const F3 n_out = n;  // outward normal, before the face flip: what the sphere's (u, v) is taken from
     // Hit::new, trace.rs:59-76: front face from the (shading) normal (Q4)
     const bool front = dot(ray.d, n) < 0.0f;
     if (!front) n = neg(n);
 
-    const F3 albedo = f3(m);
+    const F3 albedo = EXT ? texture_color(sc, mat, f3(m), type == 0u, n_out, p) : f3(m);
     if (kind == 3) {  // DiffuseLight: emits on both faces, never scatters (material.rs:66-72, 94)
         lsum = lsum + thr * albedo;
         return false;  // the reference re-traces this ray up to depth 40 to the same end (Q1)

@@ -45,7 +45,7 @@ struct DevScene {
     const float4* tri_shade;    // 3 per leaf slot: vertex normals n0 n1 n2; [0].w = material id bits
     const int4* loose;          // spheres/quads tested by every ray before traversal: type, index, rank, surface id
     const uint4* loose_rec;     // the same, self-contained (kLooseRecQuads uint4 each): {type, index, rank, material},
-                                //   then the sphere's c.xyz r + gate lo hi or the quad's normal d q A B + gate lo hi as doubles; the
+                                //   then the sphere's c.xyz r + gate lo hi + centre at time 1, or the quad's normal d q A B + gate lo hi, as doubles; the
                                 //   persistent kernels stage these in LDS
     uint32_t n_loose;
     uint32_t has_tree;          // 0: no surface lives in the render tree (all are loose)
@@ -59,6 +59,15 @@ struct DevScene {
                                 //   q and q+u+v, which is too small for a parallelogram whose sides share an axis
     const int32_t* sphere_mat;  // material id per sphere
     const int32_t* quad_mat;    // material id per quad
+    // textures and moving spheres (the EXT builds of the kernels; `ext` == 0 means none are present)
+    uint32_t ext;
+    const double* sphere_end;   // 3 per sphere: centre at ray time 1 (Sphere::moving, surfaces.rs:43-54)
+    const float4* mat_tex;      // 2 per material: {texture kind, table/image index, -, -} (as bits), {albedo2.xyz, -}
+    const double* mat_scale;    // 2 per material: tex_scale, 1 / tex_scale
+    const float4* perlin_vec;   // 256 per noise table
+    const int32_t* perlin_perm; // 3 x 256 per noise table
+    const uint8_t* image_rgb;   // all images' pixels, back to back
+    const uint4* image_dims;    // per image: byte offset, width, height, -
     const float4* materials;    // 1 per material: albedo.xyz, w = fuzz | refractive index
     const int32_t* mat_kind;    // RT_MAT_* per material
     const int32_t* slot_surface;  // surface id per leaf slot

@@ -58,7 +58,7 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int STACK, bool STATS, bool DIRECT>
+template <int STACK, bool STATS, bool DIRECT, bool EXT>
 __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         } else if (!run_shade) {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (node < 0) {
-                leaf_step<STATS>(sc, ray, sr, 0.001f, ~node, best, st);
+                leaf_step<STATS, EXT>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = stack_pop(stack, kBlock, sp);
             }
         } else {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
                 F3 lsum = {0.f, 0.f, 0.f};  // a path contributes once, where it ends
-                alive = shade_bounce<DIRECT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+                alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth, rp.max_depth);
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
                     float* a = acc + (size_t)(pix >> 6) * 192u + (pix & 63u);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                 if (alive) {
                     if (STATS) n_segments++;
                     closest_reset(best);
-                    loose_hits<STATS>(lds_loose, sc.n_loose, ray, 0.001f, best, st);
+                    loose_hits<STATS, EXT>(lds_loose, sc.n_loose, ray, 0.001f, best, st);
                     if (sc.has_tree) {
                         sr = slab_ray(ray);
                         sp = 0;
@@ -257,8 +257,13 @@ __global__ void resolve_kernel(const float* __restrict__ acc, uint32_t width, ui
 template <int STACK, bool STATS, bool DIRECT>
 static void launch_one(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
                        float* d_acc, DevCounters* counters, uint32_t* work_counter, hipStream_t stream) {
-    hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT>), dim3(blocks), dim3(kBlock), 0, stream, sc, rp,
-                       plan, d_acc, counters, work_counter);
+    // scenes with textures or moving spheres run the EXT build; the others keep the lean one
+    if (sc.ext)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true>), dim3(blocks), dim3(kBlock), 0, stream,
+                           sc, rp, plan, d_acc, counters, work_counter);
+    else
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false>), dim3(blocks), dim3(kBlock), 0, stream,
+                           sc, rp, plan, d_acc, counters, work_counter);
 }
 
 template <int STACK>

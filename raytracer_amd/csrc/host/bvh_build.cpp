@@ -135,9 +135,9 @@ Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
     switch (s.type) {
         case RT_SURF_SPHERE: {
             const rt_sphere& sp = d.spheres[s.index];
-            V3 c = v3(sp.center), r{sp.radius, sp.radius, sp.radius};
+            V3 c = v3(sp.center), c1 = sp.moving ? v3(sp.center1) : c, r{sp.radius, sp.radius, sp.radius};
             Aabb b{c - r, c + r};  // a negative radius yields an inverted box, as in the reference
-            return b.merge(b);
+            return b.merge(Aabb{c1 - r, c1 + r});  // surfaces.rs:57-69: the boxes at ray time 0 and 1
         }
         case RT_SURF_TRIANGLE: {
             const rt_triangle& t = d.triangles[s.index];
@@ -157,7 +157,8 @@ Aabb true_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
         case RT_SURF_SPHERE: {
             const rt_sphere& sp = d.spheres[s.index];
             const double r = std::fabs(sp.radius);
-            return {v3(sp.center) - V3{r, r, r}, v3(sp.center) + V3{r, r, r}};
+            const V3 c = v3(sp.center), c1 = sp.moving ? v3(sp.center1) : c;
+            return {vmin(c, c1) - V3{r, r, r}, vmax(c, c1) + V3{r, r, r}};
         }
         case RT_SURF_QUAD: {
             const rt_quad& q = d.quads[s.index];

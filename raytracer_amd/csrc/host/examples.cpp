@@ -1,7 +1,7 @@
 // Procedural example scenes: Example::scene (scene/example.rs:69-79) for the examples whose surfaces and
-// materials the render path covers — `one-weekend` (example.rs:84-142, the CLI's default scene, main.rs:102-106)
-// and `cornell` (example.rs:262-329).  The others need textures, moving spheres or volumes and
-// are refused by name.
+// materials the render path covers — `one-weekend` (example.rs:84-142, the CLI's default scene, main.rs:102-106),
+// `random-spheres`, `two-spheres`, `two-perlin`, `cornell` and `earth`.  `cornell-smoke` and `final-scene` need
+// volumes and are refused by name.
 //
 // The reference draws one-weekend from rand::thread_rng(), so no two of its runs show the same scene; here
 // the draws come from a splitmix64 stream seeded by the caller, in the reference's order of draws.
@@ -9,6 +9,7 @@
 // are baked into the quads, as the YAML loader does for `box` (load.rs:90-156).
 #include <cmath>
 #include <stdexcept>
+#include <utility>
 
 #include "scene_host.h"
 
@@ -102,6 +103,97 @@ void one_weekend(double aspect_ratio, uint64_t seed, HostScene& hs) {
     add_sphere(hs, V3{4, 1, 0}, 1.0, add_material(hs, RT_MAT_METAL, V3{0.7, 0.6, 0.5}, 0.0));
 }
 
+int add_textured(HostScene& hs, int texture, V3 even, V3 odd, double scale, int index) {
+    const int m = add_material(hs, RT_MAT_LAMBERTIAN, even, 0);
+    rt_material& mm = hs.materials[(size_t)m];
+    mm.texture = texture;
+    mm.albedo2[0] = odd.x, mm.albedo2[1] = odd.y, mm.albedo2[2] = odd.z;
+    mm.tex_scale = scale;
+    mm.tex_index = index;
+    return m;
+}
+
+// PerlinNoise::new, material.rs:289-309: 256 unit vectors from U[-1,1)^3, three shuffles of 0..255
+int add_perlin(HostScene& hs, Draws& rng) {
+    rt_perlin p{};
+    for (int i = 0; i < 256; ++i) {
+        const V3 v = unit(V3{rng.range(-1.0, 1.0), rng.range(-1.0, 1.0), rng.range(-1.0, 1.0)});
+        p.ranvec[i][0] = v.x, p.ranvec[i][1] = v.y, p.ranvec[i][2] = v.z;
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int i = 0; i < 256; ++i) p.perm[a][i] = i;
+        for (int i = 255; i > 0; --i) {  // Fisher-Yates, as SliceRandom::shuffle does
+            const int j = (int)(rng.next() * (double)(i + 1));
+            std::swap(p.perm[a][i], p.perm[a][j]);
+        }
+    }
+    hs.perlin.push_back(p);
+    return (int)hs.perlin.size() - 1;
+}
+
+// example.rs:145-206: one-weekend with a checkered ground and bouncing (moving) diffuse spheres
+void random_spheres(double aspect_ratio, uint64_t seed, HostScene& hs) {
+    hs.desc.camera = build_camera(20.0, aspect_ratio, V3{13, 2, 3}, V3{0, 0, 0}, V3{0, 1, 0}, 0.1, true, 10.0);
+    hs.desc.background[0] = 0.7, hs.desc.background[1] = 0.8, hs.desc.background[2] = 1.0;
+    Draws rng{seed};
+    add_sphere(hs, V3{0, -1000, 0}, 1000.0, add_textured(hs, RT_TEX_CHECKER, V3{0.2, 0.3, 0.1}, V3{0.9, 0.9, 0.9}, 0.32, 0));
+    for (int a = -11; a < 11; ++a)
+        for (int b = -11; b < 11; ++b) {
+            const double choose = rng.next();
+            const double cx = a + 0.9 * rng.next();
+            const double cz = b + 0.9 * rng.next();
+            const V3 centre{cx, 0.2, cz};
+            if (!(length(centre - V3{4.0, 0.2, 0.0}) > 0.9)) continue;
+            if (choose < 0.8) {
+                const V3 p{rng.next(), rng.next(), rng.next()}, q{rng.next(), rng.next(), rng.next()};
+                const int m = add_material(hs, RT_MAT_LAMBERTIAN, V3{p.x * q.x, p.y * q.y, p.z * q.z}, 0);
+                const V3 centre2 = centre + V3{0, rng.range(0.0, 0.5), 0};
+                add_sphere(hs, centre, 0.2, m);
+                rt_sphere& sp = hs.spheres.back();  // Sphere::moving(center, center2, ...)
+                sp.moving = 1;
+                sp.center1[0] = centre2.x, sp.center1[1] = centre2.y, sp.center1[2] = centre2.z;
+            } else if (choose < 0.95) {
+                const V3 albedo{rng.range(0.5, 1.0), rng.range(0.5, 1.0), rng.range(0.5, 1.0)};
+                add_sphere(hs, centre, 0.2, add_material(hs, RT_MAT_METAL, albedo, rng.range(0.0, 0.5)));
+            } else {
+                add_sphere(hs, centre, 0.2, add_material(hs, RT_MAT_DIELECTRIC, V3{1, 1, 1}, 1.5));
+            }
+        }
+    add_sphere(hs, V3{-4, 1, 0}, 1.0, add_material(hs, RT_MAT_LAMBERTIAN, V3{0.05, 0.2, 0.6}, 0));
+    add_sphere(hs, V3{0, 1, 0}, 1.0, add_material(hs, RT_MAT_DIELECTRIC, V3{1, 1, 1}, 1.5));
+    add_sphere(hs, V3{4, 1, 0}, 1.0, add_material(hs, RT_MAT_METAL, V3{0.7, 0.6, 0.5}, 0.0));
+}
+
+void two_spheres(double aspect_ratio, HostScene& hs) {  // example.rs:208-234
+    hs.desc.camera = build_camera(20.0, aspect_ratio, V3{13, 2, 3}, V3{0, 0, 0}, V3{0, 1, 0}, 0.0, false, 0.0);
+    hs.desc.background[0] = 0.7, hs.desc.background[1] = 0.8, hs.desc.background[2] = 1.0;
+    const int checker = add_textured(hs, RT_TEX_UV_CHECKER, V3{0.2, 0.3, 0.1}, V3{0.9, 0.9, 0.9}, 30.0, 0);
+    add_sphere(hs, V3{0, -10, 0}, 10.0, checker);
+    add_sphere(hs, V3{0, 10, 0}, 10.0, checker);
+}
+
+void two_perlin_spheres(double aspect_ratio, uint64_t seed, HostScene& hs) {  // example.rs:236-260
+    hs.desc.camera = build_camera(20.0, aspect_ratio, V3{13, 2, 3}, V3{0, 0, 0}, V3{0, 1, 0}, 0.0, false, 0.0);
+    hs.desc.background[0] = 0.7, hs.desc.background[1] = 0.8, hs.desc.background[2] = 1.0;
+    Draws rng{seed};
+    const int noise = add_perlin(hs, rng);
+    const int perlin = add_textured(hs, RT_TEX_MARBLE, V3{1, 1, 1}, V3{0, 0, 0}, 4.0, noise);
+    add_sphere(hs, V3{0, -1000, 0}, 1000.0, perlin);
+    add_sphere(hs, V3{0, 2, 0}, 2.0, perlin);
+}
+
+// example.rs:405-428.  The reference reads ./scenes/res/earth.png, which its repository does not ship: the
+// load fails, earth_texture() falls back to an empty image (example.rs:430-438) and Image::color_at shades
+// (0, 1, 1) (material.rs:390-392).  That is what is reproduced: an empty image.  The globe's two Rotated
+// wrappers only turn the texture, so they have no effect on it.
+void earth(double aspect_ratio, HostScene& hs) {
+    hs.desc.camera = build_camera(20.0, aspect_ratio, V3{0, 0, 12}, V3{0, 0, 0}, V3{0, 1, 0}, 0.0, false, 0.0);
+    hs.desc.background[0] = 0.7, hs.desc.background[1] = 0.8, hs.desc.background[2] = 1.0;
+    hs.images.push_back(rt_image{nullptr, 0, 0});
+    hs.image_data.emplace_back();
+    add_sphere(hs, V3{0, 0, 0}, 2.0, add_textured(hs, RT_TEX_IMAGE, V3{0, 1, 1}, V3{0, 0, 0}, 1.0, 0));
+}
+
 void cornell(double aspect_ratio, HostScene& hs) {
     // Camera::builder defaults: no aperture, focus distance = |from - towards| (camera.rs:43-74)
     hs.desc.camera = build_camera(40.0, aspect_ratio, V3{278, 278, -800}, V3{278, 278, 0}, V3{0, 1, 0}, 0.0, false, 0.0);
@@ -125,10 +217,14 @@ void cornell(double aspect_ratio, HostScene& hs) {
 void example_scene(const std::string& name, double aspect_ratio, uint64_t seed, bool use_bvh, HostScene& out) {
     if (name == "one-weekend") one_weekend(aspect_ratio, seed, out);
     else if (name == "cornell") cornell(aspect_ratio, out);
-    else if (name == "random-spheres" || name == "two-spheres" || name == "two-perlin" || name == "cornell-smoke" ||
-             name == "earth" || name == "final-scene")
-        throw std::runtime_error("example `" + name + "` needs textures, moving spheres or volumes, which this build's "
-                                 "render path does not cover (supported: one-weekend, cornell)");
+    else if (name == "random-spheres") random_spheres(aspect_ratio, seed, out);
+    else if (name == "two-spheres") two_spheres(aspect_ratio, out);
+    else if (name == "two-perlin") two_perlin_spheres(aspect_ratio, seed, out);
+    else if (name == "earth") earth(aspect_ratio, out);
+    else if (name == "cornell-smoke" || name == "final-scene")
+        throw std::runtime_error("example `" + name + "` needs volumes (ConstantMedium), which this build's render path "
+                                 "does not cover (supported: one-weekend, random-spheres, two-spheres, two-perlin, "
+                                 "cornell, earth)");
     else
         throw std::runtime_error("invalid value '" + name + "' for '--example <EXAMPLE>'");  // Example::from_str
     out.desc.use_bvh = use_bvh ? 1 : 0;
