@@ -28,8 +28,10 @@ extern "C" {
 
 /* ---- flat scene description (host memory, f64 like the reference: geom.rs:19,114) ---- */
 
-enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3 };
-enum { RT_SURF_SPHERE = 0, RT_SURF_TRIANGLE = 1, RT_SURF_QUAD = 2 };
+/* RT_MAT_ISOTROPIC (material.rs:52-57, 120-123) is the phase function of a constant medium */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3, RT_MAT_ISOTROPIC = 4 };
+/* RT_SURF_MEDIUM: index into rt_scene_desc.media */
+enum { RT_SURF_SPHERE = 0, RT_SURF_TRIANGLE = 1, RT_SURF_QUAD = 2, RT_SURF_MEDIUM = 3 };
 
 /* Texture, material.rs:183-222.  Only Lambertian materials carry one other than SOLID (material.rs:23-54). */
 enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_UV_CHECKER = 2, RT_TEX_MARBLE = 3, RT_TEX_IMAGE = 4 };
@@ -56,6 +58,17 @@ typedef struct rt_sphere {
     int32_t moving;
     double center1[3];
 } rt_sphere;
+
+/* ConstantMedium, surfaces.rs:594-653: a boundary filled with an isotropic scatterer of constant density.
+ * The boundary is one sphere (spheres[first]) or the quads of one make_box (quads[first .. first+count),
+ * surfaces.rs:542-590); boundary primitives are NOT listed in `surfaces` (a scene that also shows the boundary
+ * as a surface lists a copy).  The medium itself is listed in `surfaces` as {RT_SURF_MEDIUM, index}. */
+typedef struct rt_medium {
+    int32_t boundary;  /* RT_SURF_SPHERE | RT_SURF_QUAD */
+    int32_t first, count;
+    int32_t material;  /* an RT_MAT_ISOTROPIC material */
+    double density;
+} rt_medium;
 
 /* PerlinNoise, material.rs:281-309: 256 unit vectors and three permutations of 0..255 */
 typedef struct rt_perlin {
@@ -122,6 +135,8 @@ typedef struct rt_scene_desc {
     size_t n_perlin;
     const rt_image* images;  /* images the IMAGE textures refer to */
     size_t n_images;
+    const rt_medium* media;  /* constant media (RT_SURF_MEDIUM surfaces index this) */
+    size_t n_media;
 } rt_scene_desc;
 
 /* ---- host-side loader: replaces scene::load_scene (load.rs:39-160) ---- */

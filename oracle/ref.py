@@ -26,7 +26,8 @@ def lib():
                                        C.c_size_t, dp, dp, C.c_int]
         L.ref_scene_create_ext.restype = vp
         L.ref_scene_create_ext.argtypes = [dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
-                                           C.c_size_t, dp, dp, C.c_int, dp, dp, dp, dp, C.c_size_t, dp, dp, C.c_size_t]
+                                           C.c_size_t, dp, dp, C.c_int, dp, dp, dp, dp, C.c_size_t, dp, dp, C.c_size_t,
+                                           dp, C.c_size_t]
         L.ref_scene_destroy.argtypes = [vp]
         L.ref_leaf_order.argtypes = [vp, dp, dp]
         L.ref_camera.argtypes = [vp, dp]
@@ -77,10 +78,11 @@ class RefScene:
             pp = np.ascontiguousarray(ext["perlin_perm"], dtype=np.int32)
             ib = np.ascontiguousarray(ext["image_bytes"], dtype=np.uint8)
             idm = np.ascontiguousarray(ext["image_dims"], dtype=np.int64)
-            self._keep = (me, se, pv, pp, ib, idm)
+            md = _d(ext["media"])
+            self._keep = (me, se, pv, pp, ib, idm, md)
             self._h = lib().ref_scene_create_ext(_p(m), len(m), _p(s), len(s), _p(t), len(t), _p(q), len(q), _p(sf),
                                                  len(sf), _p(bg), _p(cam), 1 if use_bvh else 0, _p(me), _p(se), _p(pv),
-                                                 _p(pp), len(pp), _p(ib), _p(idm), len(idm))
+                                                 _p(pp), len(pp), _p(ib), _p(idm), len(idm), _p(md), len(md))
         if not self._h:
             raise RuntimeError("ref_scene_create failed (bad surface index)")
 
@@ -119,7 +121,9 @@ class RefScene:
             perlin_vec=np.array(pl["ranvec"], dtype=np.float64).reshape(-1, 256, 3),
             perlin_perm=np.array(pl["perm"], dtype=np.int32).reshape(-1, 3, 256),
             image_bytes=(np.concatenate([im.reshape(-1) for im in images]) if offs else np.zeros(1, np.uint8)),
-            image_dims=np.array(dims, dtype=np.int64).reshape(-1, 3))
+            image_dims=np.array(dims, dtype=np.int64).reshape(-1, 3),
+            media=np.column_stack([desc.media[k].astype(np.float64) for k in ("boundary", "first", "count", "material",
+                                                                               "density")]).reshape(-1, 5))
         return cls(flat, use_bvh)
 
     def close(self):

@@ -187,7 +187,7 @@ struct Aabb {  // trace.rs:93-212
 };
 
 // ------------------------------------------------------------------ material.rs
-enum Kind { Lambertian = 0, Metal = 1, Dielectric = 2, DiffuseLight = 3 };
+enum Kind { Lambertian = 0, Metal = 1, Dielectric = 2, DiffuseLight = 3, Isotropic = 4 };
 enum Tex { SolidColor = 0, Checker = 1, UVChecker = 2, Marble = 3, Image = 4 };
 
 // PerlinNoise, material.rs:281-377
@@ -324,6 +324,9 @@ inline bool scatter(const Material& m, const Ray& ray, const Hit& hit, Rng& rng,
             out = Ray(hit.point, dir, ray.time);
             break;
         }
+        case Isotropic:  // material.rs:120-123: the direction is NOT normalised
+            out = Ray(hit.point, gen_in_unit_sphere(rng, sampler), ray.time);
+            break;
         default:  // DiffuseLight, material.rs:94
             return false;
     }
@@ -340,7 +343,7 @@ struct Counters {
 };
 
 struct Surface {
-    enum Type { SphereT = 0, TriangleT = 1, QuadT = 2 } type;
+    enum Type { SphereT = 0, TriangleT = 1, QuadT = 2, MediumT = 3 } type;
     int id;  // index in the scene's surface list
     const Material* material;
     // sphere
@@ -366,6 +369,8 @@ struct Surface {
 
     Aabb bounding_box() const {
         switch (type) {
+            case MediumT:  // ConstantMedium::bounding_box = the boundary's (surfaces.rs:648-653), set by the caller
+                return box;
             case SphereT: {  // surfaces.rs:57-69
                 Vec3 r{radius, radius, radius};
                 Aabb b1{center(0.0) - r, center(0.0) + r};
@@ -383,6 +388,8 @@ struct Surface {
 
     bool hit(const Ray& ray, Interval iv, Hit& out, Counters& c) const {
         switch (type) {
+            case MediumT:  // evaluated after the surface trace (Scene::media_hit), where the path's RNG is at hand
+                return false;
             case SphereT: {  // surfaces.rs:73-106; the sphere uv (:108-118) only where a texture reads it
                 c.sphere_tests++;
                 Vec3 cen = center(ray.time);
@@ -596,8 +603,56 @@ struct Camera {
 };
 
 // ------------------------------------------------------------------ scene/mod.rs
+// ConstantMedium, surfaces.rs:594-653
+struct Medium {
+    std::vector<Surface> boundary;  // one sphere, or the quads of a make_box (a Bvh of <= 8: one leaf)
+    double neg_inv_density;
+    const Material* phase;
+    int surface;  // id in the scene's surface list
+
+    // the boundary's Hittable::hit: a leaf scan with the interval narrowed to the closest so far (bvh.rs:300-314)
+    bool boundary_hit(const Ray& ray, Interval iv, Hit& out) const {
+        Counters dummy;
+        bool any = false;
+        for (const Surface& s : boundary) {
+            Hit h;
+            if (s.hit(ray, iv, h, dummy)) {
+                any = true;
+                iv.hi = h.t;
+                out = h;
+            }
+        }
+        return any;
+    }
+};
+
 struct Scene {
     std::vector<Material> materials;
+    std::vector<Medium> media;
+
+    // ConstantMedium::hit, surfaces.rs:611-646, for every medium in index order, after the surface trace.  The
+    // reference draws the free path from thread_rng() inside the traversal; here (and on the GPU) a medium
+    // whose boundary the ray crosses in front of the closest hit so far takes one uniform of the path's stream.
+    void media_hit(const Ray& ray, Interval interval, Rng& rng, bool& found, Hit& hit) const {
+        for (const Medium& m : media) {
+            Hit hit_in, hit_out;
+            if (!m.boundary_hit(ray, Interval{-INF, INF}, hit_in)) continue;
+            if (!m.boundary_hit(ray, Interval{hit_in.t + 0.0001, INF}, hit_out)) continue;
+            double t_in = std::fmax(hit_in.t, interval.lo);
+            double t_out = std::fmin(hit_out.t, found ? hit.t : interval.hi);
+            if (t_in >= t_out) continue;
+            t_in = std::fmax(t_in, 0.0);
+            const double ray_length = length(ray.dir);
+            const double distance_inside_boundary = (t_out - t_in) * ray_length;
+            const double hit_distance = m.neg_inv_density * std::log(gen_f64(rng));
+            if (hit_distance > distance_inside_boundary) continue;
+            const double t = t_in + hit_distance / ray_length;
+            hit = make_hit(ray, t, Vec3{1.0, 0.0, 0.0}, m.phase, m.surface);
+            hit.front_face = true;
+            found = true;
+        }
+    }
+
     std::vector<PerlinNoise> perlin;
     std::vector<ImageTex> images;
     std::unique_ptr<BVHNode> root;
@@ -614,7 +669,9 @@ struct Scene {
             Interval interval{0.001, INF};
             Hit hit;
             c.segments++;
-            if (root->hit(ray, interval, hit, c)) {
+            bool found = root->hit(ray, interval, hit, c);
+            if (!media.empty()) media_hit(ray, interval, rng, found, hit);
+            if (found) {
                 Vec3 emitted = emit(*hit.material, hit);
                 Vec3 att;
                 Ray scattered;
@@ -664,12 +721,14 @@ extern "C" {
 //   sphere_end  n_sph x 3 : centre at ray time 1 (Sphere::moving, surfaces.rs:43-50)
 //   perlin_vec  n_perlin x 256 x 3 doubles, perlin_perm n_perlin x 3 x 256 int32
 //   image_dims  n_images x 3 int64: byte offset into image_bytes, width, height
+//   media       n_media x 5   : boundary type (0 sphere | 2 quads), first, count, material, density; a surface
+//                               row {3, k} places medium k in the surface list
 void* ref_scene_create_ext(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,
                            const double* triangles, size_t n_tri, const double* quads, size_t n_quad,
                            const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
                            int use_bvh, const double* mat_ext, const double* sphere_end, const double* perlin_vec,
                            const int32_t* perlin_perm, size_t n_perlin, const uint8_t* image_bytes,
-                           const int64_t* image_dims, size_t n_images) {
+                           const int64_t* image_dims, size_t n_images, const double* media, size_t n_media) {
     auto sc = std::make_unique<Scene>();
     sc->perlin.resize(n_perlin);
     for (size_t k = 0; k < n_perlin; ++k) {
@@ -702,12 +761,59 @@ void* ref_scene_create_ext(const double* materials, size_t n_mat, const double* 
         }
     }
     auto V = [](const double* p) { return Vec3{p[0], p[1], p[2]}; };
+    auto make_sphere = [&](int index, Surface& s) {
+        const double* p = spheres + 5 * index;
+        s.type = Surface::SphereT;
+        s.center_start = s.center_end = V(p);  // Sphere::stationary, surfaces.rs:34-41
+        if (sphere_end) s.center_end = V(sphere_end + 3 * index);  // Sphere::moving
+        s.radius = p[3];
+        s.material = &sc->materials[(size_t)p[4]];
+    };
+    auto make_quad = [&](int index, Surface& s) {
+        const double* p = quads + 10 * index;
+        s.type = Surface::QuadT;
+        s.q = V(p), s.u = V(p + 3), s.v = V(p + 6);
+        Vec3 n = cross(s.u, s.v);  // Quad::new
+        s.normal = unit(n);
+        s.d = dot(s.normal, s.q);
+        s.w = n / dot(n, n);
+        s.material = &sc->materials[(size_t)p[9]];
+    };
+    sc->media.resize(n_media);
     std::vector<Surface> list;
     list.reserve(n_surf);
     for (size_t i = 0; i < n_surf; ++i) {
         int type = surfaces[2 * i], index = surfaces[2 * i + 1];
         Surface s{};
         s.id = (int)i;
+        if (type == 3) {
+            if ((size_t)index >= n_media) return nullptr;
+            const double* m = media + 5 * index;
+            Medium& med = sc->media[(size_t)index];
+            const int btype = (int)m[0], first = (int)m[1], count = (int)m[2];
+            s.type = Surface::MediumT;
+            s.box = Aabb::empty();
+            for (int k = 0; k < count; ++k) {
+                Surface b{};
+                b.id = (int)i;
+                if (btype == 0) {
+                    if ((size_t)(first + k) >= n_sph) return nullptr;
+                    make_sphere(first + k, b);
+                } else {
+                    if ((size_t)(first + k) >= n_quad) return nullptr;
+                    make_quad(first + k, b);
+                }
+                b.box = b.bounding_box();
+                s.box = s.box.merge(b.box);
+                med.boundary.push_back(b);
+            }
+            med.neg_inv_density = -(1.0 / m[4]);
+            med.phase = &sc->materials[(size_t)m[3]];
+            med.surface = (int)i;
+            s.material = med.phase;
+            list.push_back(s);
+            continue;
+        }
         if (type == 0) {
             if ((size_t)index >= n_sph) return nullptr;
             const double* p = spheres + 5 * index;
@@ -748,7 +854,8 @@ void* ref_scene_create(const double* materials, size_t n_mat, const double* sphe
                        const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
                        int use_bvh) {
     return ref_scene_create_ext(materials, n_mat, spheres, n_sph, triangles, n_tri, quads, n_quad, surfaces, n_surf,
-                                background, camera, use_bvh, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
+                                background, camera, use_bvh, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                                nullptr, 0);
 }
 
 void ref_scene_destroy(void* h) { delete (Scene*)h; }

@@ -43,6 +43,11 @@ class RtPerlin(C.Structure):
     _fields_ = [("ranvec", (C.c_double * 3) * 256), ("perm", (C.c_int32 * 256) * 3)]
 
 
+class RtMedium(C.Structure):
+    _fields_ = [("boundary", C.c_int32), ("first", C.c_int32), ("count", C.c_int32), ("material", C.c_int32),
+                ("density", C.c_double)]
+
+
 class RtImage(C.Structure):
     _fields_ = [("rgb", C.POINTER(C.c_uint8)), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -76,6 +81,7 @@ class RtSceneDesc(C.Structure):
         ("background", C.c_double * 3), ("camera", RtCamera), ("use_bvh", C.c_int32), ("_pad", C.c_int32),
         ("perlin", C.POINTER(RtPerlin)), ("n_perlin", C.c_size_t),
         ("images", C.POINTER(RtImage)), ("n_images", C.c_size_t),
+        ("media", C.POINTER(RtMedium)), ("n_media", C.c_size_t),
     ]
 
 
@@ -103,6 +109,7 @@ MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("texture", "<i4"), ("albedo", "<f8"
                            ("albedo2", "<f8", 3), ("tex_scale", "<f8"), ("tex_index", "<i4"), ("_pad", "<i4")])
 SPHERE_DTYPE = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("material", "<i4"), ("moving", "<i4"),
                          ("center1", "<f8", 3)])
+MEDIUM_DTYPE = np.dtype([("boundary", "<i4"), ("first", "<i4"), ("count", "<i4"), ("material", "<i4"), ("density", "<f8")])
 PERLIN_DTYPE = np.dtype([("ranvec", "<f8", (256, 3)), ("perm", "<i4", (3, 256))])
 TRIANGLE_DTYPE = np.dtype([("v", "<f8", (3, 3)), ("n", "<f8", (3, 3)), ("material", "<i4"), ("_pad", "<i4")])
 QUAD_DTYPE = np.dtype([("q", "<f8", 3), ("u", "<f8", 3), ("v", "<f8", 3), ("normal", "<f8", 3), ("d", "<f8"),
@@ -184,7 +191,7 @@ class SceneDesc:
     # -- construction from numpy arrays (synthetic scenes in tests)
     @classmethod
     def from_arrays(cls, materials, spheres, triangles, quads, surfaces, background, camera: RtCamera,
-                    use_bvh=True, perlin=None, images=()) -> "SceneDesc":
+                    use_bvh=True, perlin=None, images=(), media=None) -> "SceneDesc":
         """`perlin`: array of PERLIN_DTYPE; `images`: sequence of uint8 arrays of shape (h, w, 3)."""
         arrs = dict(
             materials=np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE),
@@ -212,6 +219,9 @@ class SceneDesc:
             arrs["images"][i].height, arrs["images"][i].width = (im.shape[0], im.shape[1]) if im.size else (0, 0)
         d.images = C.cast(arrs["images"], C.POINTER(RtImage))
         d.n_images = len(images)
+        arrs["media"] = np.ascontiguousarray(media if media is not None else np.zeros(0, MEDIUM_DTYPE), dtype=MEDIUM_DTYPE)
+        d.media = C.cast(arrs["media"].ctypes.data, C.POINTER(RtMedium))
+        d.n_media = len(arrs["media"])
         self = cls(None, arrs)
         self._struct = d
         return self
@@ -226,6 +236,7 @@ class SceneDesc:
     quads = property(lambda s: _view(s._struct.quads, s._struct.n_quads, QUAD_DTYPE))
     surfaces = property(lambda s: _view(s._struct.surfaces, s._struct.n_surfaces, SURFACE_DTYPE))
     perlin = property(lambda s: _view(s._struct.perlin, s._struct.n_perlin, PERLIN_DTYPE))
+    media = property(lambda s: _view(s._struct.media, s._struct.n_media, MEDIUM_DTYPE))
 
     @property
     def images(self):

@@ -94,6 +94,7 @@ struct rt_scene {
     std::vector<int32_t> render_ids;  // surfaces that live in the render tree
     std::vector<double> sphere_gate, quad_gate, sphere_end, mat_scale;
     std::vector<float4> mat_tex, perlin_vec;
+    std::vector<DevMedium> media;
     std::vector<int32_t> perlin_perm;
     std::vector<uint8_t> image_rgb;
     std::vector<uint4> image_dims;
@@ -139,7 +140,7 @@ void validate(const rt_scene_desc& d) {
     };
     for (size_t i = 0; i < d.n_materials; ++i) {
         const rt_material& m = d.materials[i];
-        if (m.kind < 0 || m.kind > 3) throw std::runtime_error("unknown material kind");
+        if (m.kind < 0 || m.kind > RT_MAT_ISOTROPIC) throw std::runtime_error("unknown material kind");
         if (m.texture < 0 || m.texture > RT_TEX_IMAGE) throw std::runtime_error("unknown texture kind");
         if (m.texture == RT_TEX_MARBLE && (m.tex_index < 0 || (size_t)m.tex_index >= d.n_perlin))
             throw std::runtime_error("noise table index out of range");
@@ -150,12 +151,23 @@ void validate(const rt_scene_desc& d) {
     for (size_t i = 0; i < d.n_spheres; ++i) check_mat(d.spheres[i].material);
     for (size_t i = 0; i < d.n_triangles; ++i) check_mat(d.triangles[i].material);
     for (size_t i = 0; i < d.n_quads; ++i) check_mat(d.quads[i].material);
+    for (size_t i = 0; i < d.n_media; ++i) {
+        const rt_medium& m = d.media[i];
+        check_mat(m.material);
+        if (d.materials[m.material].kind != RT_MAT_ISOTROPIC) throw std::runtime_error("a medium needs an isotropic material");
+        if (!(m.density > 0.0)) throw std::runtime_error("medium density must be positive");
+        const size_t n = m.boundary == RT_SURF_SPHERE ? d.n_spheres : m.boundary == RT_SURF_QUAD ? d.n_quads : 0;
+        if (m.first < 0 || m.count < 1 || (size_t)m.first + (size_t)m.count > n || (m.boundary == RT_SURF_SPHERE && m.count != 1))
+            throw std::runtime_error("medium boundary out of range");
+    }
+    if (d.n_media > kMaxMedia) throw std::runtime_error("too many media (at most " + std::to_string(kMaxMedia) + ")");
     for (size_t i = 0; i < d.n_surfaces; ++i) {
         const rt_surface_ref& s = d.surfaces[i];
         size_t n = s.type == RT_SURF_SPHERE ? d.n_spheres
                    : s.type == RT_SURF_TRIANGLE ? d.n_triangles
                    : s.type == RT_SURF_QUAD ? d.n_quads
-                                            : 0;
+                   : s.type == RT_SURF_MEDIUM ? d.n_media
+                                              : 0;
         if (s.index < 0 || (size_t)s.index >= n) throw std::runtime_error("surface reference out of range");
     }
 }
@@ -212,6 +224,8 @@ void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
             const rt_triangle& t = d.triangles[ref.index];
             for (int k = 0; k < 3; ++k)
                 for (int a = 0; a < 3; ++a) p64.a[3 * k + a] = t.v[k][a];
+        } else if (ref.type == RT_SURF_MEDIUM) {
+            // no deterministic hit: the parity AOV sees surfaces only (prim_hit knows no type 3)
         } else if (ref.type == RT_SURF_SPHERE) {
             const rt_sphere& sp = d.spheres[ref.index];
             for (int a = 0; a < 3; ++a) p64.a[a] = sp.center[a];
@@ -240,8 +254,10 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s) {
     const bool loose_ok = d.n_spheres + d.n_quads <= kMaxLoose;
     std::vector<int32_t>& tree_ids = s.render_ids;
     tree_ids.clear();
-    for (size_t i = 0; i < d.n_surfaces; ++i)
+    for (size_t i = 0; i < d.n_surfaces; ++i) {
+        if (d.surfaces[i].type == RT_SURF_MEDIUM) continue;  // media are evaluated after the surface trace
         if (d.surfaces[i].type == RT_SURF_TRIANGLE || !loose_ok) tree_ids.push_back((int32_t)i);
+    }
     Bvh& rb = s.render_bvh;
     if (d.use_bvh) {
         build_render_bvh(d, tree_ids, getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : kRenderLeaf, rb);
@@ -273,7 +289,8 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     s.loose.clear();
     for (size_t i = 0; i < n_surf; ++i) {
         const rt_surface_ref& ref = d.surfaces[i];
-        if (ref.type != RT_SURF_TRIANGLE && loose_ok) s.loose.push_back(int4{ref.type, ref.index, rank[i], (int32_t)i});
+        if (ref.type != RT_SURF_TRIANGLE && ref.type != RT_SURF_MEDIUM && loose_ok)
+            s.loose.push_back(int4{ref.type, ref.index, rank[i], (int32_t)i});
     }
     Bvh& rb = s.render_bvh;
     const size_t n_tree = tree_ids.size();
@@ -380,7 +397,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         if (!n.is_leaf()) continue;
         for (int32_t k = n.first; k < n.first + n.count; ++k) {
             const rt_surface_ref& ref = d.surfaces[s.bvh.order[k]];
-            if (ref.type == RT_SURF_TRIANGLE) continue;  // Triangle::bounding_box is exact
+            if (ref.type == RT_SURF_TRIANGLE || ref.type == RT_SURF_MEDIUM) continue;  // Triangle::bounding_box is exact
             double* gate = ref.type == RT_SURF_SPHERE ? &s.sphere_gate[6 * ref.index] : &s.quad_gate[6 * ref.index];
             for (int a = 0; a < 3; ++a) gate[a] = n.box.lo.get(a), gate[3 + a] = n.box.hi.get(a);
             // a leaf box that encloses the surface is crossed by every ray that hits the surface: no test needed
@@ -432,6 +449,12 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         s.mat_tex[2 * i + 1] = {(float)m.albedo2[0], (float)m.albedo2[1], (float)m.albedo2[2], 0};
         s.mat_scale[2 * i] = m.tex_scale, s.mat_scale[2 * i + 1] = 1.0 / m.tex_scale;  // f64::recip, material.rs:195
         if (m.texture != RT_TEX_SOLID) s.ext = true;
+    }
+    s.media.assign(std::max<size_t>(d.n_media, 1), DevMedium{});
+    for (size_t k = 0; k < d.n_media; ++k) {
+        const rt_medium& m = d.media[k];
+        s.media[k] = DevMedium{m.boundary, m.first, m.count, m.material, -(1.0 / m.density), 0.0};
+        s.ext = true;
     }
     s.perlin_vec.assign(256 * std::max<size_t>(d.n_perlin, 1), float4{0, 0, 0, 0});
     s.perlin_perm.assign(768 * std::max<size_t>(d.n_perlin, 1), 0);
@@ -597,6 +620,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.quad_gate = upload(*s, s->quad_gate);
         s->dev.ext = s->ext ? 1u : 0u;
         s->dev.sphere_end = upload(*s, s->sphere_end);
+        s->dev.n_media = (uint32_t)desc->n_media;
+        s->dev.media = upload(*s, s->media);
         s->dev.mat_tex = upload(*s, s->mat_tex);
         s->dev.mat_scale = upload(*s, s->mat_scale);
         s->dev.perlin_vec = upload(*s, s->perlin_vec);

@@ -481,6 +481,76 @@ __device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (2.0f * dot(v, n)
 // One bounce (one iteration of the loop at scene/mod.rs:103-125).  `lsum` gathers radiance in the forward
 // form  L += T*emitted; T *= albedo  (equal to resolve_color's back-to-front fold).  Returns whether the
 // path continues; `depth` follows the reference's counter including the metal re-sampling quirk (Q1).
+// ---- constant media (EXT builds): ConstantMedium::hit, surfaces.rs:611-646.
+// The reference evaluates a medium inside the BVH traversal and draws its free path from thread_rng() — not
+// even from the seeded generator.  Here the media are evaluated after the surface trace, in index order: a
+// medium whose boundary the ray crosses in front of the closest hit so far draws one uniform from the path's
+// own stream (the oracle does the same, so both follow the same paths).  The boundary tests keep the
+// reference's semantics: a sphere is entered at its first root whatever its sign (Interval::UNIVERSE), a box
+// of quads only at parameters >= 1e-4 (Quad::hit's own cut-off, surfaces.rs:337), so a ray that starts inside
+// a box-shaped medium sees its far wall as the entry and finds no exit: such a medium is invisible from inside.
+// The boundary crossings are a property of the ray, the free paths are drawn per attempt (a ray whose hit does
+// not scatter is traced again, see shade_bounce): media_spans does the geometry once, media_sample the draws.
+struct MediaSpans {
+    double t_in[kMaxMedia], t_out[kMaxMedia];  // t_out < t_in: the ray does not cross this medium's boundary
+};
+__device__ __forceinline__ void media_spans(const DevScene& sc, const Ray& ray, MediaSpans& sp) {
+    const D3 dd = d3(ray.d);
+    const double inf = (double)__builtin_inff();
+#pragma unroll
+    for (uint32_t k = 0; k < kMaxMedia; ++k) {
+        sp.t_in[k] = 0.0, sp.t_out[k] = -1.0;
+        if (k >= sc.n_media) continue;
+        const DevMedium m = sc.media[k];
+        if (m.boundary == 0) {
+            const double* s = sc.spheres + 4 * m.first;
+            const D3 oc = ray.o - d3(s);
+            const double a = dot(dd, dd), half_b = dot(oc, dd), c = dot(oc, oc) - s[3] * s[3];
+            const double disc = half_b * half_b - a * c;
+            if (disc > 0.0) {
+                const double root = sqrt64(disc), ia = rcp64(a);
+                const double t0 = (-half_b - root) * ia, t1 = (-half_b + root) * ia;
+                if (t1 >= t0 + 0.0001) sp.t_in[k] = t0, sp.t_out[k] = t1;  // the second Sphere::hit, on (t0 + 0.0001, inf)
+            }
+        } else {
+            double first = inf, second = inf;
+            for (int32_t q = 0; q < m.count; ++q) {
+                const double t = quad_root(sc.quads + 16 * (m.first + q), ray.o, dd, -inf, inf);
+                if (t >= 0.0 && t <= first) first = t;
+            }
+            if (first < inf) {
+                for (int32_t q = 0; q < m.count; ++q) {
+                    const double t = quad_root(sc.quads + 16 * (m.first + q), ray.o, dd, first + 0.0001, inf);
+                    if (t >= 0.0 && t <= second) second = t;
+                }
+                if (second < inf) sp.t_in[k] = first, sp.t_out[k] = second;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void media_sample(const DevScene& sc, const Ray& ray, float tmin, Rng& rng, Closest& best,
+                                             const MediaSpans& sp) {
+    const D3 dd = d3(ray.d);
+    const double inf = (double)__builtin_inff();
+#pragma unroll
+    for (uint32_t k = 0; k < kMaxMedia; ++k) {
+        if (k >= sc.n_media || !(sp.t_out[k] >= sp.t_in[k])) continue;
+        const double t_best = best.h.slot == -1 ? inf
+                              : (best.h.slot >= 0 && (best.meta & kMetaTypeMask) == 1u ? (double)best.h.t : hit_get_t64(best.h));
+        double t_in = fmax(sp.t_in[k], (double)tmin);
+        const double t_out = fmin(sp.t_out[k], t_best);
+        if (!(t_in < t_out)) continue;
+        t_in = fmax(t_in, 0.0);
+        const double len = sqrt64(dot(dd, dd));
+        const double inside = (t_out - t_in) * len;
+        const double hit_distance = sc.media[k].neg_inv_density * log((double)rng_u01(rng));
+        if (hit_distance > inside) continue;
+        const double t = t_in + hit_distance * rcp64(len);
+        best.h.t = (float)t, best.h.slot = kMediumSlot - (int)k, best.rank = -1, best.meta = 0u;
+        hit_set_t64(best.h, t);
+    }
+}
+
 // ---- textures (EXT builds): Texture::color_at, material.rs:212-221
 // PerlinNoise::noise + trilinear_interp, material.rs:325-368
 __device__ __forceinline__ float perlin_noise(const float4* vec, const int32_t* perm, F3 p) {
@@ -551,10 +621,23 @@ __device__ __forceinline__ F3 texture_color(const DevScene& sc, int mat, F3 albe
 template <bool DIRECT, bool EXT = false>
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* recs, Ray& ray, const HitRec& hit,
                                              uint32_t meta, float tmin, Rng& rng, F3& thr, F3& lsum, uint32_t& depth,
-                                             uint32_t max_depth) {
+                                             uint32_t max_depth, bool* retrace = nullptr) {
+    // `retrace` (scenes with constant media): a hit that does not scatter (a light, an absorbed metal reflection)
+    // makes the reference trace the SAME ray again, one depth unit per attempt (Q1) — and every attempt draws the
+    // media's free paths anew, so the ray may scatter in a medium instead.  With `retrace` given, such a hit
+    // returns with *retrace set and the ray unchanged, and the caller evaluates the media again; without media
+    // the attempts are identical, so the light ends the path at once and the metal re-samples its fuzz in place.
     if (hit.slot == -1) {  // escaped: (0, background), scene/mod.rs:122
         lsum = lsum + thr * f3(sc.background);
         return false;
+    }
+    if (EXT && hit.slot <= kMediumSlot) {  // scattered inside a constant medium: Isotropic, material.rs:120-123
+        const int mat = sc.media[kMediumSlot - hit.slot].material;
+        const D3 p = ray.o + hit_get_t64(hit) * d3(ray.d);
+        thr = thr * f3(sc.materials[mat]);
+        ray.o = p;
+        ray.d = rng_in_unit_sphere<DIRECT>(rng);
+        return ++depth < max_depth;
     }
     // type and material first: the material fetch then overlaps the normal fetch
     uint32_t type, index;
@@ -607,6 +690,10 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
 
     const F3 albedo = EXT ? texture_color(sc, mat, f3(m), type == 0u, n_out, p) : f3(m);
     if (kind == 3) {  // DiffuseLight: emits on both faces, never scatters (material.rs:66-72, 94)
+        if (EXT && retrace && ++depth < max_depth) {
+            *retrace = true;
+            return true;
+        }
         lsum = lsum + thr * albedo;
         return false;  // the reference re-traces this ray up to depth 40 to the same end (Q1)
     }
@@ -622,6 +709,10 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
             if (dot(dir, n) > 1e-8f) break;
             // absorbed: nothing pushed, depth += 1, same ray re-traced to the same hit, fuzz re-drawn
             if (++depth >= max_depth) return false;
+            if (EXT && retrace) {
+                *retrace = true;
+                return true;
+            }
         }
     } else {  // Dielectric, material.rs:141-181
         const float ratio = front ? fast_rcp(m.w) : m.w;

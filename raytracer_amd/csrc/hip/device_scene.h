@@ -27,6 +27,15 @@ struct Prim64 {
     double a[16];
 };
 
+// ConstantMedium (surfaces.rs:594-653): boundary = spheres[first] or quads[first .. first+count)
+struct DevMedium {
+    int32_t boundary, first, count, material;
+    double neg_inv_density;  // -(1 / d), surfaces.rs:605
+    double pad;
+};
+constexpr uint32_t kMaxMedia = 4;
+constexpr int kMediumSlot = -100;  // hit slot of medium k is kMediumSlot - k (loose primitives use -2 .. -17)
+
 struct DevCamera {
     double origin[3];  // ray origins are carried in f64 (spheres/quads are intersected in f64)
     float ll_rel[3];   // lower_left - origin            (f64 on host, then rounded)
@@ -61,6 +70,8 @@ struct DevScene {
     const int32_t* quad_mat;    // material id per quad
     // textures and moving spheres (the EXT builds of the kernels; `ext` == 0 means none are present)
     uint32_t ext;
+    uint32_t n_media;
+    const DevMedium* media;
     const double* sphere_end;   // 3 per sphere: centre at ray time 1 (Sphere::moving, surfaces.rs:43-54)
     const float4* mat_tex;      // 2 per material: {texture kind, table/image index, -, -} (as bits), {albedo2.xyz, -}
     const double* mat_scale;    // 2 per material: tex_scale, 1 / tex_scale

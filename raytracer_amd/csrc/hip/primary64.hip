@@ -47,6 +47,7 @@ __device__ inline bool aabb_hit(const double* lo, const double* hi, V o, V inv, 
 __device__ inline bool contains(double lo, double hi, double t) { return lo <= t && t <= hi; }
 
 __device__ inline double prim_hit(const Prim64& p, V o, V d, double t_min, double t_max) {
+    if (p.type == 3) return -1.0;  // a constant medium has no deterministic hit: the AOV sees surfaces only
     if (p.type == 1) {  // Triangle::hit
         const V v0 = mk(p.a), v1 = mk(p.a + 3), v2 = mk(p.a + 6);
         const V e1 = v1 - v0, e2 = v2 - v0;

@@ -133,7 +133,24 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
                 F3 lsum = {0.f, 0.f, 0.f};  // a path contributes once, where it ends
-                alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth, rp.max_depth);
+                if (EXT && sc.n_media) {
+                    // the media are evaluated after the surface trace, and again on every re-trace of a ray whose
+                    // hit did not scatter (see shade_bounce)
+                    const Closest surface = best;
+                    MediaSpans spans;
+                    media_spans(sc, ray, spans);
+                    bool again;
+                    do {
+                        again = false;
+                        best = surface;
+                        media_sample(sc, ray, 0.001f, rng, best, spans);
+                        alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
+                                                          rp.max_depth, &again);
+                    } while (again && alive);
+                } else {
+                    alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
+                                                      rp.max_depth);
+                }
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
                     float* a = acc + (size_t)(pix >> 6) * 192u + (pix & 63u);

@@ -144,6 +144,12 @@ Aabb surface_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
             V3 a = v3(t.v[0]), b = v3(t.v[1]), c = v3(t.v[2]);
             return {vmin(vmin(a, b), c), vmax(vmax(a, b), c)};
         }
+        case RT_SURF_MEDIUM: {  // ConstantMedium::bounding_box = its boundary's (surfaces.rs:648-653)
+            const rt_medium& m = d.media[s.index];
+            Aabb box = Aabb::empty();
+            for (int32_t k = 0; k < m.count; ++k) box = box.merge(surface_bounds(d, rt_surface_ref{m.boundary, m.first + k}));
+            return box;
+        }
         default: {
             const rt_quad& q = d.quads[s.index];
             V3 a = v3(q.q), b = a + v3(q.u) + v3(q.v);
@@ -164,6 +170,12 @@ Aabb true_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
             const rt_quad& q = d.quads[s.index];
             const V3 a = v3(q.q), u = v3(q.u), v = v3(q.v);
             return {vmin(vmin(a, a + u), vmin(a + v, a + u + v)), vmax(vmax(a, a + u), vmax(a + v, a + u + v))};
+        }
+        case RT_SURF_MEDIUM: {
+            const rt_medium& m = d.media[s.index];
+            Aabb box = Aabb::empty();
+            for (int32_t k = 0; k < m.count; ++k) box = box.merge(true_bounds(d, rt_surface_ref{m.boundary, m.first + k}));
+            return box;
         }
         default:
             return surface_bounds(d, s);

@@ -1,7 +1,6 @@
 // Procedural example scenes: Example::scene (scene/example.rs:69-79) for the examples whose surfaces and
 // materials the render path covers — `one-weekend` (example.rs:84-142, the CLI's default scene, main.rs:102-106),
-// `random-spheres`, `two-spheres`, `two-perlin`, `cornell` and `earth`.  `cornell-smoke` and `final-scene` need
-// volumes and are refused by name.
+// `random-spheres`, `two-spheres`, `two-perlin`, `cornell`, `cornell-smoke`, `earth` and `final-scene`.
 //
 // The reference draws one-weekend from rand::thread_rng(), so no two of its runs show the same scene; here
 // the draws come from a splitmix64 stream seeded by the caller, in the reference's order of draws.
@@ -10,6 +9,7 @@
 #include <cmath>
 #include <stdexcept>
 #include <utility>
+#include <vector>
 
 #include "scene_host.h"
 
@@ -54,8 +54,9 @@ void add_quad(HostScene& hs, V3 q, V3 u, V3 v, int material) {
 }
 
 // make_box (surfaces.rs:542-590), Rotated::new about the box's centroid (surfaces.rs:507-534) by
-// `degrees` around +y, then Translated (surfaces.rs:468-491).
-void add_box(HostScene& hs, V3 a, V3 b, int material, double degrees, V3 offset) {
+// `degrees` around +y, then Translated (surfaces.rs:468-491).  `as_surfaces` == false adds the quads as the
+// boundary of a medium only (not hittable themselves).
+void add_box(HostScene& hs, V3 a, V3 b, int material, double degrees, V3 offset, bool as_surfaces = true) {
     const V3 lo = vmin(a, b), hi = vmax(a, b);
     const V3 dx{hi.x - lo.x, 0, 0}, dy{0, hi.y - lo.y, 0}, dz{0, 0, hi.z - lo.z};
     const V3 centre = 0.5 * (lo + hi);  // the quads' boxes are padded symmetrically: same centroid
@@ -64,7 +65,8 @@ void add_box(HostScene& hs, V3 a, V3 b, int material, double degrees, V3 offset)
         const V3 p0 = rotate_point(rot, centre, q) + offset;
         const V3 p1 = rotate_point(rot, centre, q + u) + offset;
         const V3 p2 = rotate_point(rot, centre, q + v) + offset;
-        add_quad(hs, p0, p1 - p0, p2 - p0, material);
+        if (as_surfaces) add_quad(hs, p0, p1 - p0, p2 - p0, material);
+        else hs.quads.push_back(make_quad(p0, p1 - p0, p2 - p0, material));
     };
     put(V3{lo.x, lo.y, hi.z}, dx, dy);              // front
     put(V3{hi.x, lo.y, hi.z}, -1.0 * dz, dy);       // right
@@ -72,6 +74,16 @@ void add_box(HostScene& hs, V3 a, V3 b, int material, double degrees, V3 offset)
     put(V3{lo.x, lo.y, lo.z}, dz, dy);              // left
     put(V3{lo.x, hi.y, hi.z}, dx, -1.0 * dz);       // top
     put(V3{lo.x, lo.y, lo.z}, dx, dz);              // bottom
+}
+
+// ConstantMedium::new(boundary, d, albedo), surfaces.rs:601-608, over boundary primitives added just before
+void add_medium(HostScene& hs, int boundary, int first, int count, double density, V3 albedo) {
+    rt_medium m{};
+    m.boundary = boundary, m.first = first, m.count = count;
+    m.material = add_material(hs, RT_MAT_ISOTROPIC, albedo, 0);
+    m.density = density;
+    hs.surfaces.push_back(rt_surface_ref{RT_SURF_MEDIUM, (int32_t)hs.media.size()});
+    hs.media.push_back(m);
 }
 
 void one_weekend(double aspect_ratio, uint64_t seed, HostScene& hs) {
@@ -212,6 +224,75 @@ void cornell(double aspect_ratio, HostScene& hs) {
     add_box(hs, V3{0, 0.001, 0}, V3{165, 165, 165}, white, -18.0, V3{130, 0, 65});
 }
 
+// example.rs:331-403: the Cornell box with its two boxes turned into smoke (black) and fog (white)
+void cornell_smoke(double aspect_ratio, HostScene& hs) {
+    hs.desc.camera = build_camera(40.0, aspect_ratio, V3{278, 278, -800}, V3{278, 278, 0}, V3{0, 1, 0}, 0.0, false, 0.0);
+    hs.desc.background[0] = hs.desc.background[1] = hs.desc.background[2] = 0.0;
+    const int red = add_material(hs, RT_MAT_LAMBERTIAN, V3{0.65, 0.05, 0.05}, 0);
+    const int white = add_material(hs, RT_MAT_LAMBERTIAN, V3{0.73, 0.73, 0.73}, 0);
+    const int green = add_material(hs, RT_MAT_LAMBERTIAN, V3{0.12, 0.45, 0.15}, 0);
+    const int light = add_material(hs, RT_MAT_DIFFUSE_LIGHT, V3{7, 7, 7}, 0);
+    add_quad(hs, V3{555, 0, 0}, V3{0, 555, 0}, V3{0, 0, 555}, green);
+    add_quad(hs, V3{0, 0, 0}, V3{0, 555, 0}, V3{0, 0, 555}, red);
+    add_quad(hs, V3{113, 554, 127}, V3{330, 0, 0}, V3{0, 0, 305}, light);
+    add_quad(hs, V3{0, 555, 0}, V3{555, 0, 0}, V3{0, 0, 555}, white);
+    add_quad(hs, V3{0, 0, 0}, V3{555, 0, 0}, V3{0, 0, 555}, white);
+    add_quad(hs, V3{0, 0, 555}, V3{555, 0, 0}, V3{0, 555, 0}, white);
+    int first = (int)hs.quads.size();
+    add_box(hs, V3{0, 0.001, 0}, V3{165, 333, 165}, white, 15.0, V3{265, 0, 295}, false);
+    add_medium(hs, RT_SURF_QUAD, first, 6, 0.01, V3{0, 0, 0});
+    first = (int)hs.quads.size();
+    add_box(hs, V3{0, 0.001, 0}, V3{165, 165, 165}, white, -18.0, V3{130, 0, 65}, false);
+    add_medium(hs, RT_SURF_QUAD, first, 6, 0.01, V3{1, 1, 1});
+}
+
+// example.rs:466-572: every feature at once.  SceneBuilder's default background is black.
+void final_scene(double aspect_ratio, uint64_t seed, HostScene& hs) {
+    hs.desc.camera = build_camera(40.0, aspect_ratio, V3{478, 278, -600}, V3{278, 278, 0}, V3{0, 1, 0}, 0.0, false, 0.0);
+    hs.desc.background[0] = hs.desc.background[1] = hs.desc.background[2] = 0.0;
+    Draws rng{seed};
+    const int ground = add_material(hs, RT_MAT_LAMBERTIAN, V3{0.48, 0.83, 0.53}, 0);
+    for (int i = 0; i < 20; ++i)
+        for (int j = 0; j < 20; ++j) {
+            const double w = 100.0, x0 = -1000.0 + i * w, z0 = -1000.0 + j * w, y1 = rng.range(1.0, 101.0);
+            add_box(hs, V3{x0, 0.0, z0}, V3{x0 + w, y1, z0 + w}, ground, 0.0, V3{0, 0, 0});
+        }
+    add_quad(hs, V3{123, 554, 147}, V3{300, 0, 0}, V3{0, 0, 265}, add_material(hs, RT_MAT_DIFFUSE_LIGHT, V3{7, 7, 7}, 0));
+    add_sphere(hs, V3{400, 400, 200}, 50.0, add_material(hs, RT_MAT_LAMBERTIAN, V3{0.7, 0.3, 0.1}, 0));
+    hs.spheres.back().moving = 1;  // Sphere::moving(center1, center1 + (30, 0, 0), ...)
+    hs.spheres.back().center1[0] = 430.0;
+    add_sphere(hs, V3{260, 150, 45}, 50.0, add_material(hs, RT_MAT_DIELECTRIC, V3{1, 1, 1}, 1.5));
+    add_sphere(hs, V3{0, 150, 145}, 50.0, add_material(hs, RT_MAT_METAL, V3{0.8, 0.8, 0.9}, 1.0));
+    // a glass ball filled with blue smoke: the boundary is a surface AND (a copy) the medium's boundary
+    const int glass = add_material(hs, RT_MAT_DIELECTRIC, V3{1, 1, 1}, 1.5);
+    add_sphere(hs, V3{360, 150, 145}, 70.0, glass);
+    auto boundary_sphere = [&](V3 c, double r) {
+        rt_sphere sp{};
+        sp.center[0] = sp.center1[0] = c.x, sp.center[1] = sp.center1[1] = c.y, sp.center[2] = sp.center1[2] = c.z;
+        sp.radius = r, sp.material = glass;
+        hs.spheres.push_back(sp);
+        return (int)hs.spheres.size() - 1;
+    };
+    add_medium(hs, RT_SURF_SPHERE, boundary_sphere(V3{360, 150, 145}, 70.0), 1, 0.2, V3{0.2, 0.4, 0.9});
+    add_medium(hs, RT_SURF_SPHERE, boundary_sphere(V3{0, 0, 0}, 5000.0), 1, 0.0001, V3{1, 1, 1});  // thin mist everywhere
+    hs.images.push_back(rt_image{nullptr, 0, 0});  // earth_texture(): see earth() above
+    hs.image_data.emplace_back();
+    add_sphere(hs, V3{400, 200, 400}, 100.0, add_textured(hs, RT_TEX_IMAGE, V3{0, 1, 1}, V3{0, 0, 0}, 1.0, 0));
+    const int noise = add_perlin(hs, rng);
+    add_sphere(hs, V3{220, 280, 300}, 80.0, add_textured(hs, RT_TEX_MARBLE, V3{1, 1, 1}, V3{0, 0, 0}, 0.1, noise));
+    // 1000 small spheres in a 165-cube, the cluster turned 15 degrees about its bounding box's centre, then moved
+    const int white = add_material(hs, RT_MAT_LAMBERTIAN, V3{0.73, 0.73, 0.73}, 0);
+    std::vector<V3> pts(1000);
+    V3 lo{INFINITY, INFINITY, INFINITY}, hi{-INFINITY, -INFINITY, -INFINITY};
+    for (V3& p : pts) {
+        p = V3{rng.range(0.0, 165.0), rng.range(0.0, 165.0), rng.range(0.0, 165.0)};
+        lo = vmin(lo, p - V3{10, 10, 10}), hi = vmax(hi, p + V3{10, 10, 10});
+    }
+    const V3 centre = lo + 0.5 * (hi - lo);  // Aabb::centroid of the cluster's box (Rotated::new, surfaces.rs:507-517)
+    const Quat rot = Quat::rotation(V3{0, 1, 0}, 15.0 * 0.017453292519943295);
+    for (const V3& p : pts) add_sphere(hs, rotate_point(rot, centre, p) + V3{-100, 270, 395}, 10.0, white);
+}
+
 }  // namespace
 
 void example_scene(const std::string& name, double aspect_ratio, uint64_t seed, bool use_bvh, HostScene& out) {
@@ -221,10 +302,8 @@ void example_scene(const std::string& name, double aspect_ratio, uint64_t seed, 
     else if (name == "two-spheres") two_spheres(aspect_ratio, out);
     else if (name == "two-perlin") two_perlin_spheres(aspect_ratio, seed, out);
     else if (name == "earth") earth(aspect_ratio, out);
-    else if (name == "cornell-smoke" || name == "final-scene")
-        throw std::runtime_error("example `" + name + "` needs volumes (ConstantMedium), which this build's render path "
-                                 "does not cover (supported: one-weekend, random-spheres, two-spheres, two-perlin, "
-                                 "cornell, earth)");
+    else if (name == "cornell-smoke") cornell_smoke(aspect_ratio, out);
+    else if (name == "final-scene") final_scene(aspect_ratio, seed, out);
     else
         throw std::runtime_error("invalid value '" + name + "' for '--example <EXAMPLE>'");  // Example::from_str
     out.desc.use_bvh = use_bvh ? 1 : 0;

@@ -262,6 +262,7 @@ void HostScene::sync_desc() {
     desc.triangles = triangles.data(), desc.n_triangles = triangles.size();
     desc.quads = quads.data(), desc.n_quads = quads.size();
     desc.surfaces = surfaces.data(), desc.n_surfaces = surfaces.size();
+    desc.media = media.data(), desc.n_media = media.size();
     desc.perlin = perlin.data(), desc.n_perlin = perlin.size();
     for (size_t i = 0; i < images.size() && i < image_data.size(); ++i) images[i].rgb = image_data[i].data();
     desc.images = images.data(), desc.n_images = images.size();

@@ -17,6 +17,7 @@ struct HostScene {
     std::vector<rt_triangle> triangles;
     std::vector<rt_quad> quads;
     std::vector<rt_surface_ref> surfaces;
+    std::vector<rt_medium> media;
     std::vector<rt_perlin> perlin;
     std::vector<rt_image> images;
     std::vector<std::vector<uint8_t>> image_data;  // pixels behind `images`

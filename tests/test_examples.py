@@ -16,6 +16,8 @@ CAMERAS = {  # [vfov, aspect, from, towards, aperture, has_focus, focus] as each
     "two-perlin": lambda a: [20.0, a, 13, 2, 3, 0, 0, 0, 0.0, 0.0, 0.0],         # example.rs:237-240
     "cornell": lambda a: [40.0, a, 278, 278, -800, 278, 278, 0, 0.0, 0.0, 0.0],  # example.rs:263-266
     "earth": lambda a: [20.0, a, 0, 0, 12, 0, 0, 0, 0.0, 0.0, 0.0],              # example.rs:406-409
+    "cornell-smoke": lambda a: [40.0, a, 278, 278, -800, 278, 278, 0, 0.0, 0.0, 0.0],  # example.rs:332-335
+    "final-scene": lambda a: [40.0, a, 478, 278, -600, 278, 278, 0, 0.0, 0.0, 0.0],    # example.rs:467-470
 }
 
 
@@ -81,16 +83,33 @@ def test_textured_and_moving_examples_structure(ra):
     assert d.materials["texture"][0] == ra.RT_TEX_IMAGE and len(d.images) == 1 and d.images[0].size == 0
 
 
+def test_media_examples_structure(ra):
+    d = ra.example_scene("cornell-smoke", 1.0)
+    med, mats = d.media, d.materials
+    assert len(med) == 2 and med["boundary"].tolist() == [2, 2] and med["count"].tolist() == [6, 6]
+    assert med["density"].tolist() == [0.01, 0.01]
+    assert mats["kind"][med["material"]].tolist() == [4, 4]                       # Isotropic phase functions
+    assert mats["albedo"][med["material"]].tolist() == [[0, 0, 0], [1, 1, 1]]    # smoke and fog
+    assert len(d.quads) == 18 and len(d.surfaces) == 8                            # boundary quads are not surfaces
+    assert d.surfaces["type"].tolist() == [2] * 6 + [3, 3]
+    assert mats["albedo"][3].tolist() == [7, 7, 7]
+    d = ra.example_scene("final-scene", 1.0, seed=9)
+    assert len(d.quads) == 2400 + 1 and len(d.spheres) == 6 + 2 + 1000 and len(d.media) == 2  # 6 shown, 2 boundary copies, the cluster
+    assert d.media["density"].tolist() == [0.2, 0.0001] and d.spheres["radius"][d.media["first"]].tolist() == [70, 5000]
+    assert np.array_equal(d.background, [0, 0, 0]) and d.spheres["moving"].sum() == 1
+    tops = (d.quads["q"][:2400, 1] + d.quads["u"][:2400, 1] + d.quads["v"][:2400, 1]).reshape(400, 6).max(1)
+    assert np.all((tops >= 1.0) & (tops < 101.0))                                # box heights, example.rs:484
+    cluster = d.spheres["center"][-1000:]
+    assert np.all(d.spheres["radius"][-1000:] == 10) and np.all(np.abs(cluster.mean(0) - [-100 + 82.5, 270 + 82.5, 395 + 82.5]) < 12)
+
+
 def test_examples_camera_matches_oracle_and_unsupported_names_are_refused(ra, ref):
     for name, aspect in (("one-weekend", 1.5), ("cornell", 1.0), ("random-spheres", 1.5), ("two-spheres", 1.5),
-                         ("two-perlin", 1.5), ("earth", 1.5)):
+                         ("two-perlin", 1.5), ("earth", 1.5), ("cornell-smoke", 1.0), ("final-scene", 1.0)):
         d = ra.example_scene(name, aspect)
         cam = ref.RefScene.from_desc(d, CAMERAS[name](aspect)).camera()
         for k in ("origin", "lower_left", "horizontal", "vertical", "u", "v", "w"):
             assert np.array_equal(np.array(getattr(d.camera, k)), cam[k]), (name, k)
-    for name in ("cornell-smoke", "final-scene"):
-        with pytest.raises(ra.api.RtError, match="needs volumes"):
-            ra.example_scene(name, 1.5)
     with pytest.raises(ra.api.RtError, match="invalid value 'teapot'"):
         ra.example_scene("teapot", 1.5)
 
@@ -98,7 +117,8 @@ def test_examples_camera_matches_oracle_and_unsupported_names_are_refused(ra, re
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,w,h,sn", [("one-weekend", 150, 100, 4), ("cornell", 96, 96, 5),
                                          ("random-spheres", 150, 100, 4), ("two-spheres", 120, 80, 4),
-                                         ("two-perlin", 120, 80, 4), ("earth", 90, 60, 3)])
+                                         ("two-perlin", 120, 80, 4), ("earth", 90, 60, 3),
+                                         ("cornell-smoke", 96, 96, 5), ("final-scene", 100, 100, 4)])
 def test_example_renders_match_the_oracle(ra, ref, name, w, h, sn):
     from test_gpu_parity import F32_ID_MISMATCH, T_REL, _check_image
 
