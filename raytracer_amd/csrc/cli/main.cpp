@@ -1,6 +1,7 @@
 // `raytracer` — command line of the reference (clap derive, main.rs:23-66) over the C ABI in include/rt.h.
 // Same flag names, defaults and conflict rule; same stderr "Done in …" line (main.rs:190) and RGB8 PNG
 // (main.rs:192-200).  Extra flags: --gpus N, --kernel persistent|wavefront|pool, --sampler direct|reference, --dump-primary FILE, --json.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -49,7 +50,7 @@ void help() {
         "      --scene <SCENE>                A scene file to load from configuration\n"
         "      --example <EXAMPLE>            An example scene from the book, generated at random: one-weekend\n"
         "                                     (default without --scene) or cornell; drawn from --seed\n"
-        "      --no-progress                  Accepted for compatibility\n"
+        "      --no-progress                  Disables the progress block (shown for long renders, once a second)\n"
         "      --no-bvh                       Disables the use of the bvh acceleration structure\n"
         "      --gpus <N>                     Shard the strata over N GPUs [default: 1]\n"
         "      --kernel <persistent|wavefront|pool>\n"
@@ -172,30 +173,64 @@ int main(int argc, char** argv) {
     }
     // The reference seeds from OS entropy without --seed; any fixed default is as good, and reproducible.
     const uint64_t seed = o.has_seed ? o.seed : 0x5eed5eedull;
+    const auto render_start = std::chrono::steady_clock::now();
 
+    // Long jobs are rendered in batches of strata so that the progress block of progress.rs:63-97 (elapsed,
+    // remaining, samples/sec, remaining pixels; once a second) can be shown; short ones go in one launch.
+    const double total_samples = (double)width * (double)height * (double)sn * (double)sn;
+    const uint32_t n_strata = sn * sn;
+    const uint32_t batches = (!o.no_progress && total_samples > 8e9) ? std::min<uint32_t>(32u, std::max(1u, n_strata / (uint32_t)o.gpus)) : 1u;
+    std::vector<float> sum(3 * width * height, 0.f);
     std::vector<std::vector<float>> parts((size_t)o.gpus, std::vector<float>(3 * width * height));
     std::vector<rt_stats> stats((size_t)o.gpus);
-    std::vector<int> rc((size_t)o.gpus, 0);
-    std::vector<std::string> errs((size_t)o.gpus);
-    std::vector<std::thread> pool;
-    for (int g = 0; g < o.gpus; ++g) {
-        pool.emplace_back([&, g]() {
-            rt_render_params p{};
-            p.width = (uint32_t)width, p.height = (uint32_t)height, p.sn = sn, p.max_depth = max_depth;
-            p.seed = seed, p.stratum_begin = (uint32_t)g, p.stratum_step = (uint32_t)o.gpus, p.kernel = o.kernel, p.sampler = o.sampler;
-            rc[(size_t)g] = rt_render(scenes[(size_t)g], &p, parts[(size_t)g].data(), &stats[(size_t)g]);
-            if (rc[(size_t)g]) errs[(size_t)g] = rt_last_error();
-        });
-    }
-    for (auto& th : pool) th.join();
-    for (int g = 0; g < o.gpus; ++g)
-        if (rc[(size_t)g]) {
-            std::fprintf(stderr, "Error: render on GPU %d: %s\n", g, errs[(size_t)g].c_str());
-            return 1;
+    double kernel_ms_total = 0;
+    auto last_report = start;
+    bool reported = false;
+    for (uint32_t b = 0; b < batches; ++b) {
+        std::vector<int> rc((size_t)o.gpus, 0);
+        std::vector<std::string> errs((size_t)o.gpus);
+        std::vector<std::thread> pool;
+        for (int g = 0; g < o.gpus; ++g) {
+            pool.emplace_back([&, g]() {
+                rt_render_params p{};
+                p.width = (uint32_t)width, p.height = (uint32_t)height, p.sn = sn, p.max_depth = max_depth;
+                p.seed = seed, p.kernel = o.kernel, p.sampler = o.sampler;
+                p.stratum_begin = b * (uint32_t)o.gpus + (uint32_t)g, p.stratum_step = batches * (uint32_t)o.gpus;
+                rc[(size_t)g] = rt_render(scenes[(size_t)g], &p, parts[(size_t)g].data(), &stats[(size_t)g]);
+                if (rc[(size_t)g]) errs[(size_t)g] = rt_last_error();
+            });
         }
-    std::vector<float>& sum = parts[0];
-    for (int g = 1; g < o.gpus; ++g)
-        for (size_t i = 0; i < sum.size(); ++i) sum[i] += parts[(size_t)g][i];
+        for (auto& th : pool) th.join();
+        double batch_ms = 0;
+        for (int g = 0; g < o.gpus; ++g) {
+            if (rc[(size_t)g]) {
+                std::fprintf(stderr, "Error: render on GPU %d: %s\n", g, errs[(size_t)g].c_str());
+                return 1;
+            }
+            for (size_t i = 0; i < sum.size(); ++i) sum[i] += parts[(size_t)g][i];
+            batch_ms = std::fmax(batch_ms, stats[(size_t)g].kernel_ms);
+        }
+        kernel_ms_total += batch_ms;
+        const auto now = std::chrono::steady_clock::now();
+        if (batches > 1 && b + 1 < batches && std::chrono::duration<double>(now - last_report).count() >= 1.0) {
+            last_report = now;
+            const double elapsed = std::chrono::duration<double>(now - start).count();
+            const double done = (double)(b + 1) / (double)batches;
+            const double render_elapsed = std::chrono::duration<double>(now - render_start).count();
+            const double remaining = render_elapsed * (1.0 - done) / done;
+            auto fmt = [](double sec, char* buf, size_t n) {  // format_duration, progress.rs:100-110
+                const unsigned long s = (unsigned long)sec, hh = s / 3600, mm = (s - hh * 3600) / 60, ss = s - mm * 60 - hh * 3600;
+                if (hh > 0) std::snprintf(buf, n, "%02lu:%02lu:%02lu", hh, mm, ss);
+                else std::snprintf(buf, n, "%02lu:%02lu", mm, ss);
+            };
+            char e[32], r[32];
+            fmt(elapsed, e, sizeof e), fmt(remaining, r, sizeof r);
+            if (!reported) std::fprintf(stderr, "\n\n\n\n");
+            reported = true;
+            std::fprintf(stderr, "\x1b[4A    Elapsed Time: %s    \n  Remaining Time: %s    \n   Samples / sec: %.0f    \nRemaining Pixels: %.0f    \n",
+                         e, r, total_samples * done / render_elapsed, (double)width * (double)height * (1.0 - done));
+        }
+    }
 
     std::vector<uint8_t> rgb(3 * width * height);
     if (rt_tonemap_rgb8(sum.data(), (uint32_t)width, (uint32_t)height, (uint64_t)sn * sn, rgb.data())) return die("tonemap");
@@ -205,8 +240,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "\nDone in %.2fs (%.0f rays/s)\n", elapsed, rays / elapsed);  // main.rs:190
     if (rt_write_png(o.output.c_str(), rgb.data(), (uint32_t)width, (uint32_t)height)) return die("could not write image");
     if (o.json) {
-        double kernel_ms = 0;
-        for (auto& s : stats) kernel_ms = std::fmax(kernel_ms, s.kernel_ms);
+        const double kernel_ms = kernel_ms_total;
         std::printf("{\"samples\": %.0f, \"wall_s\": %.4f, \"kernel_ms\": %.3f, \"msamples_per_s\": %.3f, \"gpus\": %d}\n",
                     rays, elapsed, kernel_ms, rays / (kernel_ms * 1e3), o.gpus);
     }
