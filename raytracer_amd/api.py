@@ -124,6 +124,26 @@ class RtError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so, and a process that first loads
+    /opt/rocm's copy (through librt_amd.so) and then imports torch finds no GPU in torch.  When torch is
+    installed but not imported yet, map its runtime first so that librt_amd.so binds to the same one."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for root in (spec.submodule_search_locations or []) if spec else []:
+        path = os.path.join(root, "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return
+
+
 def lib() -> C.CDLL:
     """Load librt_amd.so; raises (loudly) when it has not been built."""
     global _lib
@@ -132,6 +152,7 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(or `make -C raytracer_amd/csrc`). There is no fallback path.")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, u64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
     L.rt_load_scene.argtypes = [C.c_char_p, dbl, i32, C.POINTER(C.POINTER(RtSceneDesc))]

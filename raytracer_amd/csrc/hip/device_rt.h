@@ -58,6 +58,12 @@ struct D3 {
     double x, y, z;
 };
 __device__ __forceinline__ D3 d3(const double* p) { return {p[0], p[1], p[2]}; }
+// Wave-uniform read-only data addressed through the constant address space: the compiler fetches it with
+// scalar loads into SGPRs (one fetch per wave through the scalar cache) instead of 64 identical lane reads.
+typedef const double __attribute__((address_space(4)))* UniformF64;
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));  // uint4 is a class: no copy out of address space 4
+typedef const U32x4 __attribute__((address_space(4)))* UniformRecs;
+__device__ __forceinline__ D3 d3(UniformF64 p) { return {p[0], p[1], p[2]}; }
 __device__ __forceinline__ D3 d3(F3 v) { return {(double)v.x, (double)v.y, (double)v.z}; }
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -187,8 +193,8 @@ __device__ __forceinline__ double sqrt64(double x) {  // x > 0
 
 // Sphere, f64 (surfaces.rs:73-106).  Returns the first root inside [tmin, tmax], or -1.
 // Sphere::center, surfaces.rs:52-54; the stationary builds read c0 only.
-template <bool EXT>
-__device__ __forceinline__ D3 sphere_centre(const double* c0, const double* c1, float time) {
+template <bool EXT, class P0, class P1>
+__device__ __forceinline__ D3 sphere_centre(P0 c0, P1 c1, float time) {
     if (!EXT) return d3(c0);
     const double t = (double)time;
     return (1.0 - t) * d3(c0) + t * d3(c1);
@@ -233,17 +239,17 @@ __device__ __attribute__((noinline)) bool leaf_gate_hit(const double* gate, D3 o
     }
     return true;
 }
-template <bool EXT>
-__device__ __forceinline__ double sphere_root_gated(const double* sp, const double* gate, const double* c1, float time,
-                                                    D3 o, D3 d, double tmin, double tmax) {
+template <bool EXT, class P>
+__device__ __forceinline__ double sphere_root_gated(P sp, P gate, P c1, float time, D3 o, D3 d, double tmin, double tmax) {
     double t = sphere_root(sphere_centre<EXT>(sp, c1, time), sp[3], o, d, tmin, tmax);
     // gate[0] == -inf: the host found the leaf's box to enclose the sphere, so every hit passes
-    if (t >= 0.0 && sp[3] < 0.0 && gate[0] != -__builtin_inf() && !leaf_gate_hit(gate, o, d, tmin)) t = -1.0;
+    if (t >= 0.0 && sp[3] < 0.0 && gate[0] != -__builtin_inf() && !leaf_gate_hit((const double*)gate, o, d, tmin)) t = -1.0;
     return t;
 }
 
 // Quad, f64 (surfaces.rs:330-354).  alpha = w·(p×v) = p·(v×w), beta = w·(u×p) = p·(w×u).
-__device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double tmin, double tmax) {
+template <class P>
+__device__ __forceinline__ double quad_root(P q, D3 o, D3 d, double tmin, double tmax) {
     D3 n = d3(q);
     double denom = dot(n, d);
     if (fabs(denom) < 1e-8) return -1.0;
@@ -256,10 +262,10 @@ __device__ __forceinline__ double quad_root(const double* q, D3 o, D3 d, double 
     return t;
 }
 
-__device__ __forceinline__ double quad_root_gated(const double* q, const double* gate, D3 o, D3 d, double tmin,
-                                                  double tmax) {
+template <class P>
+__device__ __forceinline__ double quad_root_gated(P q, P gate, D3 o, D3 d, double tmin, double tmax) {
     double t = quad_root(q, o, d, tmin, tmax);
-    if (t >= 0.0 && gate[0] != -__builtin_inf() && !leaf_gate_hit(gate, o, d, tmin)) t = -1.0;
+    if (t >= 0.0 && gate[0] != -__builtin_inf() && !leaf_gate_hit((const double*)gate, o, d, tmin)) t = -1.0;
     return t;
 }
 
@@ -296,12 +302,17 @@ __device__ __forceinline__ void closest_reset(Closest& c) {
 __device__ __forceinline__ const double* loose_data(const uint4* recs, uint32_t i) {
     return (const double*)(recs + kLooseRecQuads * i + 1);
 }
-template <bool STATS, bool EXT = false>
-__device__ __forceinline__ void loose_hits(const uint4* recs, uint32_t n_loose, const Ray& ray, float tmin,
+__device__ __forceinline__ UniformF64 loose_data(UniformRecs recs, uint32_t i) {
+    return (UniformF64)(recs + kLooseRecQuads * i + 1);
+}
+__device__ __forceinline__ UniformRecs uniform_recs(const uint4* p) { return (UniformRecs)(uintptr_t)p; }
+// `recs`: const uint4* (LDS or global, read lane by lane) or UniformRecs (global, read once per wave).
+template <bool STATS, bool EXT = false, class Recs>
+__device__ __forceinline__ void loose_hits(Recs recs, uint32_t n_loose, const Ray& ray, float tmin,
                                            Closest& best, TraceStats& st) {
     const D3 dd = d3(ray.d);
     for (uint32_t i = 0; i < n_loose; ++i) {
-        const uint4 m = recs[kLooseRecQuads * i];
+        const auto m = recs[kLooseRecQuads * i];
         double t;
         if (m.x == 0u) {
             if (STATS) st.spheres++;

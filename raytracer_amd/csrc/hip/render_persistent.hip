@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                 if (alive) {
                     if (STATS) n_segments++;
                     closest_reset(best);
-                    loose_hits<STATS, EXT>(lds_loose, sc.n_loose, ray, 0.001f, best, st);
+                    loose_hits<STATS, EXT>(uniform_recs(sc.loose_rec), sc.n_loose, ray, 0.001f, best, st);
                     if (sc.has_tree) {
                         sr = slab_ray(ray);
                         sp = 0;

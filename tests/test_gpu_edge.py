@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import synth
-from conftest import scene_path
+from conftest import ROOT, scene_path
 from test_gpu_parity import F32_ID_MISMATCH, T_REL, _check_image, _same_image
 
 pytestmark = pytest.mark.gpu
@@ -129,3 +129,25 @@ def test_4k_frame_and_eight_strata_slices(ra):
     parts = sum(s.render(3840, 2160, 4, stratum_begin=g, stratum_step=8)[0].astype(np.float64) for g in range(8))
     assert np.allclose(parts, full, rtol=1e-5, atol=1e-5)
     s.close()
+
+
+def test_library_before_torch_shares_one_hip_runtime():
+    """A fresh process that loads librt_amd.so first and imports torch afterwards must still see the GPU from
+    torch (api._share_torch_hip_runtime): two HIP runtimes in one process leave torch without devices."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import raytracer_amd as ra\n"
+        "s = ra.Scene(ra.load_scene('scenes/quads.yaml', 1.5), 0)\n"
+        "img, st = s.render(60, 40, 2)\n"
+        "import torch\n"
+        "fb = torch.zeros((40, 60, 3), dtype=torch.float32, device='cuda:0')\n"
+        "s.render_device(fb.data_ptr(), 60, 40, 2, stream=torch.cuda.current_stream().cuda_stream)\n"
+        "import numpy as np\n"
+        "assert np.allclose(fb.cpu().numpy(), img, rtol=1e-5, atol=1e-6)\n"
+        "print('ok')\n"
+    ) % ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
