@@ -727,6 +727,24 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                                 c.stage_trips[k] ? (double)c.stage_lanes[k] / (double)c.stage_trips[k] : 0.0,
                                 c.stage_trips[k] ? (double)c.stage_cycles[k] / (double)c.stage_trips[k] : 0.0,
                                 (double)c.stage_cycles[k] * 1e-9);
+                if (getenv("RT_STAGE_DEBUG")) {
+                    for (int pass = 0; pass < 2; ++pass) {
+                        fprintf(stderr, pass ? "[waves finished, per 0.5 ms]" : "[waves out of work, per 0.5 ms]");
+                        int last = 63;
+                        while (last > 0 && (pass ? c.finish_hist : c.exhaust_hist)[last] == 0) --last;
+                        for (int k = 0; k <= last; ++k) fprintf(stderr, " %u", (pass ? c.finish_hist : c.exhaust_hist)[k]);
+                        fprintf(stderr, "\n");
+                    }
+                    fprintf(stderr, "[drain time, per 0.25 ms]");
+                    int last = 63;
+                    while (last > 0 && c.drain_hist[last] == 0) --last;
+                    for (int k = 0; k <= last; ++k) fprintf(stderr, " %u", c.drain_hist[k]);
+                    fprintf(stderr, "\n%u waves drained for more than 2 ms\n", c.n_late);
+                    for (unsigned k = 0; k < std::min(c.n_late, 32u); ++k)
+                        fprintf(stderr, "  out of work %.2f ms, done %.2f ms; node/leaf/shade trips %llu %llu %llu lanes %llu %llu %llu\n",
+                                c.late[k][0] * 1e-5, c.late[k][1] * 1e-5, c.late[k][2], c.late[k][3], c.late[k][4],
+                                c.late[k][5], c.late[k][6], c.late[k][7]);
+                }
                 if (getenv("RT_STAGE_DEBUG") && c.stage_trips[2])
                     fprintf(stderr, "[shade trip] bounce+accumulate %.0f, regenerate %.0f, loose+bounds %.0f cycles/trip\n",
                             (double)c.stage_cycles[4] / (double)c.stage_trips[2],

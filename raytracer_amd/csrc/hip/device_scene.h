@@ -104,6 +104,13 @@ struct DevCounters {  // one instance in HBM, bumped with one atomic per wave at
     unsigned int work;  // chunk cursor of the persistent kernel
     unsigned int pad;
     unsigned long long stage_trips[8], stage_lanes[8], stage_cycles[8];  // persistent kernels, counting build: per stage
+    // counting build: when the waves ran out of work and when they finished (0.5 ms buckets from the first wave's
+    // start, 100 MHz wall clock) — the launch's tail
+    unsigned long long t_first_inv;  // ~(earliest start)
+    unsigned int exhaust_hist[64], finish_hist[64];
+    unsigned int drain_hist[64];          // finish - out-of-work, 0.25 ms buckets
+    unsigned int n_late, pad2;
+    unsigned long long late[32][8];       // waves that drained for > 2 ms: times, trips and lanes per stage while draining
 };
 
 }  // namespace rt

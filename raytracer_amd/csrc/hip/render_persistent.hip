@@ -26,15 +26,21 @@ constexpr int kBlock = 256;
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
-constexpr uint32_t kChunkStrata = 16;  // strata per chunk (a chunk is 64 pixels x this many strata)
+constexpr uint32_t kChunkStrata = 16;  // strata per chunk in the first phase (a chunk is 64 pixels x this many strata)
+constexpr int kPhases = 4;
 
 struct PersistentPlan {
     int shade_threshold;     // run the shade stage once this many lanes wait in it (or nothing else can run)
     int node_bias;           // node stage runs when n_node * node_bias >= n_leaf * 4
     uint32_t tiles_x, n_tiles;
     uint32_t my_strata;      // strata this call renders (begin, begin+step, ...)
-    uint32_t groups;         // ceil(my_strata / kChunkStrata)
-    uint32_t n_chunks;       // n_tiles * groups
+    // Guided hand-out in kPhases phases of shrinking chunks (16, 8, 4, 2 strata): phase p covers the strata
+    // [phase_first[p], phase_first[p + 1]) of every tile in groups [phase_end[p - 1], phase_end[p]).  The waves
+    // then run dry within a small chunk's time of each other; with 16-strata chunks throughout, the waves still
+    // busy with a heavy chunk when the counter ran out cost 5 ms of a 33 ms launch on lucy.yaml, 13 of 71 on
+    // teapot.yaml (1/8 of the 1024 strata, as an 8-GPU run gives each rank).
+    uint32_t phase_first[5], phase_end[4], phase_strata[4];
+    uint32_t n_chunks;       // n_tiles * phase_end[3]
 };
 
 // Lane stages, encoded in `node`: an inner node id (>= 0) = one node_step pending; a leaf reference (< 0,
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     const uint64_t seed = ((uint64_t)rp.seed_hi << 32) | rp.seed_lo;
 
     // wave-uniform cursor over the current chunk
-    uint32_t chunk_tile = 0, chunk_group = 0, next_j = 0, chunk_total = 0;
+    uint32_t chunk_tile = 0, chunk_first = 0, next_j = 0, chunk_total = 0;  // chunk_first: its first stratum
     bool exhausted = false;
 
     // per-lane path + traversal state
@@ -96,10 +102,13 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
     int sp = 0;
     TraceStats st;
     uint32_t n_segments = 0;
-    uint32_t trips[3] = {0, 0, 0}, lanes_on[3] = {0, 0, 0};  // counting build: stage occupancy
-    unsigned long long cycles[3] = {0, 0, 0}, t_begin = 0;
+    uint32_t trips[4] = {0, 0, 0, 0}, lanes_on[4] = {0, 0, 0, 0};  // counting build: stage occupancy 
+    unsigned long long cycles[4] = {0, 0, 0, 0}, t_begin = 0;
     unsigned long long sub_cycles[3] = {0, 0, 0};  // shade trip split: bounce+accumulate, regenerate, loose+bounds
     int stage_run = 0;
+    unsigned long long t_exhausted = 0;
+    uint32_t drain_trips[3] = {0, 0, 0}, drain_lanes[3] = {0, 0, 0};
+    if (STATS && lane == 0) atomicMax(&counters->t_first_inv, ~wall_clock64());
 
     // Every trip runs ONE stage for the lanes waiting in it — the stage most lanes wait in — so the lanes that
     // execute a trip all do the same small piece of work (one node, one primitive, or one shade+raygen),
@@ -115,18 +124,21 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         if (STATS) t_begin = __builtin_readcyclecounter();
         if (!run_shade && n_node * plan.node_bias >= n_leaf * 4) {
             if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
+            if (STATS && exhausted) drain_trips[0]++, drain_lanes[0] += n_node;
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
 #pragma unroll 1
             for (int k = 0; k < RT_NODE_STEPS; ++k)
                 if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, kBlock, sp, st);
         } else if (!run_shade) {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
+            if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
             if (node < 0) {
                 leaf_step<STATS, EXT>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = stack_pop(stack, kBlock, sp);
             }
         } else {
             if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
+            if (STATS && exhausted) drain_trips[2]++, drain_lanes[2] += n_shade;
             const bool mine = node == kStageShade;
             unsigned long long t_part = 0;
             if (STATS) t_part = __builtin_readcyclecounter();
@@ -178,15 +190,18 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                     c = __builtin_amdgcn_readfirstlane(c);
                     if (c >= plan.n_chunks) {
                         exhausted = true;
+                        if (STATS) t_exhausted = wall_clock64();
                         break;
                     }
                     // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
-                    chunk_group = c / plan.n_tiles;
-                    chunk_tile = c - chunk_group * plan.n_tiles;
+                    const uint32_t group = c / plan.n_tiles;
+                    chunk_tile = c - group * plan.n_tiles;
                     flush_tile(acc, wacc, acc_tile, lane);
                     acc_tile = chunk_tile;
-                    const uint32_t strata_here = min(kChunkStrata, plan.my_strata - chunk_group * kChunkStrata);
-                    chunk_total = 64u * strata_here;
+                    int p = 0;
+                    while (p < kPhases - 1 && group >= plan.phase_end[p]) ++p;
+                    chunk_first = plan.phase_first[p] + (group - (p ? plan.phase_end[p - 1] : 0u)) * plan.phase_strata[p];
+                    chunk_total = 64u * min(plan.phase_strata[p], plan.phase_first[p + 1] - chunk_first);
                     next_j = 0;
                 }
                 const uint32_t avail = chunk_total - next_j;
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                     const uint32_t py = (chunk_tile / plan.tiles_x) * 8u + (in_tile >> 3);  // image row, 0 = top
                     if (px < rp.width && py < rp.height) {
                         const uint32_t stratum =
-                            rp.stratum_begin + (chunk_group * kChunkStrata + (j >> 6)) * rp.stratum_step;
+                            rp.stratum_begin + (chunk_first + (j >> 6)) * rp.stratum_step;
                         pix = chunk_tile * 64u + in_tile;  // slot in the tile-planar accumulator
                         // the stream key is the reference's idx: pi = idx % W, pj = H - idx/W - 1
                         rng_init(rng, seed, py * rp.width + px, stratum);
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         }
         if (STATS) {
             const unsigned long long t_end = __builtin_readcyclecounter();
-            for (int k = 0; k < 3; ++k) cycles[k] += stage_run == k ? t_end - t_begin : 0ull;
+            for (int k = 0; k < 4; ++k) cycles[k] += stage_run == k ? t_end - t_begin : 0ull;
         }
     }
 
@@ -249,12 +264,28 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
         atomicAdd(&counters->tri_tests, (unsigned long long)st.tris);
         atomicAdd(&counters->sphere_tests, (unsigned long long)st.spheres);
         atomicAdd(&counters->quad_tests, (unsigned long long)st.quads);
+        if (lane == 0) {
+            const unsigned long long t0 = ~__hip_atomic_load(&counters->t_first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long bucket = 50000ull;  // 0.5 ms at 100 MHz
+            atomicAdd(&counters->exhaust_hist[min((unsigned long long)63, (t_exhausted - t0) / bucket)], 1u);
+            const unsigned long long t_fin = wall_clock64();
+            atomicAdd(&counters->finish_hist[min((unsigned long long)63, (t_fin - t0) / bucket)], 1u);
+            atomicAdd(&counters->drain_hist[min((unsigned long long)63, (t_fin - t_exhausted) / 25000ull)], 1u);
+            if (t_fin - t_exhausted > 200000ull) {
+                const uint32_t k = atomicAdd(&counters->n_late, 1u);
+                if (k < 32u) {
+                    unsigned long long* r = counters->late[k];
+                    r[0] = t_exhausted - t0, r[1] = t_fin - t0;
+                    for (int q = 0; q < 3; ++q) r[2 + q] = drain_trips[q], r[5 + q] = drain_lanes[q];
+                }
+            }
+        }
         if (lane == 0)
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 atomicAdd(&counters->stage_trips[k], (unsigned long long)trips[k]);
                 atomicAdd(&counters->stage_lanes[k], (unsigned long long)lanes_on[k]);
                 atomicAdd(&counters->stage_cycles[k], cycles[k]);
-                atomicAdd(&counters->stage_cycles[4 + k], sub_cycles[k]);
+                if (k < 3) atomicAdd(&counters->stage_cycles[4 + k], sub_cycles[k]);
             }
     }
 }
@@ -305,9 +336,22 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
     plan.my_strata =
         rp.stratum_begin >= rp.n_strata ? 0 : (rp.n_strata - rp.stratum_begin + rp.stratum_step - 1) / rp.stratum_step;
-    plan.groups = (plan.my_strata + kChunkStrata - 1) / kChunkStrata;
-    if ((uint64_t)plan.n_tiles * plan.groups >= (1ull << 32)) return hipErrorInvalidValue;
-    plan.n_chunks = plan.n_tiles * plan.groups;
+    // A phase leaves kTailChunks of its own chunks' worth of strata to the finer phases after it (a heavy chunk
+    // takes several times the mean), but never more than half of what is left; the last phase takes the rest.
+    const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K"))) : 4u;
+    const uint32_t first_chunk = kChunkStrata;
+    uint32_t done = 0, groups = 0;
+    for (int p = 0; p < kPhases; ++p) {
+        const uint32_t per = std::max(2u, first_chunk >> p), left = plan.my_strata - done;
+        const uint32_t take = p == kPhases - 1 ? left : (left - std::min(left / 2u, tail_chunks * per)) / per * per;
+        plan.phase_first[p] = done, plan.phase_strata[p] = per;
+        groups += (take + per - 1) / per;
+        plan.phase_end[p] = groups;
+        done += take;
+    }
+    plan.phase_first[kPhases] = plan.my_strata;
+    if ((uint64_t)plan.n_tiles * groups >= (1ull << 32)) return hipErrorInvalidValue;
+    plan.n_chunks = plan.n_tiles * groups;
 
     hipError_t e = hipMemsetAsync(d_acc, 0, persistent_acc_bytes(rp.width, rp.height), stream);
     if (e != hipSuccess) return e;
