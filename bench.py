@@ -40,6 +40,59 @@ def reduce_framebuffer(fb, world: int) -> None:
         dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
 
 
+class FramePipeline:
+    """Two framebuffers in turn: frame i's sum-reduce runs (on RCCL's own stream) beside frame i+1's render, and
+    frame i is finished — reduce awaited, `finish(buffer)` called, e.g. the tonemap — after frame i+1's render
+    was issued.  A buffer is rendered into again only after the frame it held was finished, in stream order.
+    With one rank there is nothing to overlap: a frame is finished in its own step."""
+
+    def __init__(self, buffers, world: int, render, finish):
+        self.buffers, self.world, self.render, self.finish = buffers, world, render, finish
+        self.work = [None] * len(buffers)
+        self.open = [False] * len(buffers)
+        self.i = 0
+
+    def _finish(self, k: int) -> None:
+        if self.work[k] is not None:
+            self.work[k].wait()  # the current stream waits for the reduce; the host does not
+            self.work[k] = None
+        if self.open[k]:
+            self.finish(self.buffers[k])
+            self.open[k] = False
+
+    def step(self):
+        k = self.i % len(self.buffers)
+        self.i += 1
+        self._finish(k)  # no-op unless the pipeline is deeper than its buffers
+        out = self.render(self.buffers[k])
+        self.open[k] = True
+        if self.world > 1:
+            import torch.distributed as dist
+
+            self.work[k] = dist.reduce(self.buffers[k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            self._finish((k - 1) % len(self.buffers))  # the frame before: its reduce ran beside this render
+        else:
+            self._finish(k)
+        return out
+
+    def drain(self) -> None:
+        n = len(self.buffers)
+        for j in range(n):  # oldest frame first
+            self._finish((self.i + j) % n)
+
+
+def handout_groups(strata: int) -> int:
+    """Chunks per tile of the persistent kernel's guided hand-out (render_persistent.hip: phases of 16, 8, 4 and
+    2 strata; a phase leaves four of its chunks' worth, at most half of the rest, to the finer ones)."""
+    done = groups = 0
+    for p in range(4):
+        per, left = max(2, 16 >> p), strata - done
+        take = left if p == 3 else (left - min(left // 2, 4 * per)) // per * per
+        groups += (take + per - 1) // per
+        done += take
+    return groups
+
+
 def flops_per_sample(st) -> float:
     """sum over bounces [N_box*24 + N_tri*60 + N_sph*30 + N_quad*45 + shade*60] + raygen*40,
     with N_box = 2 child boxes per visited node."""
@@ -133,22 +186,30 @@ def main() -> None:
     setup_s = time.perf_counter() - t0
     info = scene.info()
 
-    fb = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+    fbs = [torch.empty((h, w, 3), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    fb = fbs[0]
     rgb8 = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
     begin, step_ = strata_slice(rank, world)
     stream = torch.cuda.current_stream(dev).cuda_stream
     kernel_ms = []
 
-    def one_step():
-        st = scene.render_device(fb.data_ptr(), w, h, sn, max_depth=40, seed=args.seed, stratum_begin=begin,
+    def render(buf):
+        st = scene.render_device(buf.data_ptr(), w, h, sn, max_depth=40, seed=args.seed, stratum_begin=begin,
                                  stratum_step=step_, kernel=kernel, stream=stream, sampler=sampler)
         kernel_ms.append(st.kernel_ms)  # HIP events on `stream`, around this step's render kernels
-        reduce_framebuffer(fb, world)
-        if rank == 0:
-            ra.api._check(ra.lib().rt_tonemap_rgb8_device(fb.data_ptr(), w, h, sn * sn, rgb8.data_ptr(), stream))
         return st
 
+    def tonemap(buf):
+        if rank == 0:
+            ra.api._check(ra.lib().rt_tonemap_rgb8_device(buf.data_ptr(), w, h, sn * sn, rgb8.data_ptr(), stream))
+
+    # a step = render this rank's strata slice of one frame + the frame's sum-reduce + tonemap on rank 0; with
+    # several ranks the reduce of one frame overlaps the render of the next (FramePipeline)
+    frames = FramePipeline(fbs, world, render, tonemap)
+    one_step = frames.step
+
     def fence():
+        frames.drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -181,14 +242,15 @@ def main() -> None:
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved_tflops = fl * my_samples / avg_kernel_s / 1e12
     # HBM-side traffic the algorithm needs per launch (persistent kernels): clear of the tile-planar accumulator
-    # (12 B/pixel), one 768-byte flush of a wave's tile sums per chunk of 1024 samples, and the resolve pass
+    # (12 B/pixel), one 768-byte flush of a wave's tile sums per chunk (1024 samples, fewer at the tail), and the resolve pass
     # (12 B/pixel read + 12 B/pixel written).  The wavefront form instead adds 12 B per sample directly and
     # streams its path-state queues (~216 B per segment).
     seg_per_sample = cnt.segments / max(cnt.samples, 1)
     if kernel == ra.RT_KERNEL_WAVEFRONT:
         hbm_bytes = 12.0 * w * h + 12.0 * my_samples + 216.0 * seg_per_sample * my_samples
     else:
-        hbm_bytes = 36.0 * w * h + 0.75 * my_samples
+        tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        hbm_bytes = 36.0 * w * h + 768.0 * tiles * handout_groups(my_samples // (w * h))
 
     if rank == 0:
         workload = (f"scenes/{args.scene}.yaml {w}x{h} {sn * sn} spp, max_depth 40, "

@@ -58,3 +58,61 @@ def test_strata_slice_covers_each_stratum_once():
                 b, s = bench.strata_slice(r, world)
                 seen += list(range(b, n, s))
             assert sorted(seen) == list(range(n))
+
+
+def _pipeline_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+
+    frame = [0]
+    finished = []
+
+    def render(buf):
+        frame[0] += 1
+        buf.fill_(float((rank + 1) * frame[0]))  # rank r's "slice" of frame f
+        return frame[0]
+
+    def finish(buf):
+        finished.append(buf.clone())
+
+    pipe = bench.FramePipeline([torch.zeros(4, 3), torch.zeros(4, 3)], world, render, finish)
+    order = [pipe.step() for _ in range(5)]
+    assert order == [1, 2, 3, 4, 5]
+    assert len(finished) == 4  # the last frame's reduce is still open
+    pipe.drain()
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, torch.stack(finished).numpy())
+    dist.destroy_process_group()
+
+
+def test_frame_pipeline_overlapped_reduce_two_ranks(tmp_path):
+    """bench.py's FramePipeline: frame i's reduce is awaited after frame i+1's render was issued; every frame
+    is finished exactly once, in order, holding the sum over ranks."""
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.shape == (5, 4, 3)
+    for f in range(5):
+        assert np.all(got[f] == 3.0 * (f + 1))  # (1 + 2) * frame
+
+
+def test_frame_pipeline_single_rank_finishes_in_step():
+    import bench
+
+    log = []
+    pipe = bench.FramePipeline([torch.zeros(2)], 1, lambda b: log.append("render") or len(log), lambda b: log.append("finish"))
+    pipe.step(), pipe.step()
+    pipe.drain()
+    assert log == ["render", "finish", "render", "finish"]
+
+
+def test_handout_groups_matches_the_kernel_plan():
+    import bench
+
+    # 1024 strata: 960 in 16s, then 32 in 8s, 16 in 4s, 16 in 2s
+    assert bench.handout_groups(1024) == 60 + 4 + 4 + 8
+    assert bench.handout_groups(128) == 4 + 4 + 4 + 8
+    assert bench.handout_groups(4) == 2 and bench.handout_groups(1) == 1 and bench.handout_groups(0) == 0
