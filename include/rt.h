@@ -65,7 +65,7 @@ typedef struct rt_sphere {
  * as a surface lists a copy).  The medium itself is listed in `surfaces` as {RT_SURF_MEDIUM, index}. */
 typedef struct rt_medium {
     int32_t boundary;  /* RT_SURF_SPHERE | RT_SURF_QUAD */
-    int32_t first, count;
+    int32_t first, count; /* one sphere, or the quads of a box (at most six) */
     int32_t material;  /* an RT_MAT_ISOTROPIC material */
     double density;
 } rt_medium;

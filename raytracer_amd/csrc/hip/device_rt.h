@@ -504,18 +504,23 @@ __device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (2.0f * dot(v, n)
 // not scatter is traced again, see shade_bounce): media_spans does the geometry once, media_sample the draws.
 struct MediaSpans {
     double t_in[kMaxMedia], t_out[kMaxMedia];  // t_out < t_in: the ray does not cross this medium's boundary
+    double len, inv_len;                       // |d| and its reciprocal
 };
-__device__ __forceinline__ void media_spans(const DevScene& sc, const Ray& ray, MediaSpans& sp) {
-    const D3 dd = d3(ray.d);
+// (Not inlined, like leaf_gate_hit: the kernel's register allocation then does not have to hold this function's
+// working set — a box's six roots — next to the path state; its operands travel as plain pointers and values.)
+__device__ __attribute__((noinline)) void media_spans_impl(const DevMedium* media, uint32_t n_media, const double* spheres,
+                                                           const double* quads, D3 o, D3 dd, MediaSpans* out) {
+    MediaSpans sp;
     const double inf = (double)__builtin_inff();
+    sp.len = sqrt64(dot(dd, dd)), sp.inv_len = rcp64(sp.len);
 #pragma unroll
     for (uint32_t k = 0; k < kMaxMedia; ++k) {
         sp.t_in[k] = 0.0, sp.t_out[k] = -1.0;
-        if (k >= sc.n_media) continue;
-        const DevMedium m = sc.media[k];
+        if (k >= n_media) continue;
+        const DevMedium m = media[k];
         if (m.boundary == 0) {
-            const double* s = sc.spheres + 4 * m.first;
-            const D3 oc = ray.o - d3(s);
+            const double* s = spheres + 4 * m.first;
+            const D3 oc = o - d3(s);
             const double a = dot(dd, dd), half_b = dot(oc, dd), c = dot(oc, oc) - s[3] * s[3];
             const double disc = half_b * half_b - a * c;
             if (disc > 0.0) {
@@ -524,24 +529,30 @@ __device__ __forceinline__ void media_spans(const DevScene& sc, const Ray& ray, 
                 if (t1 >= t0 + 0.0001) sp.t_in[k] = t0, sp.t_out[k] = t1;  // the second Sphere::hit, on (t0 + 0.0001, inf)
             }
         } else {
-            double first = inf, second = inf;
-            for (int32_t q = 0; q < m.count; ++q) {
-                const double t = quad_root(sc.quads + 16 * (m.first + q), ray.o, dd, -inf, inf);
-                if (t >= 0.0 && t <= first) first = t;
+            // the six sides once: the second Quad::hit pass, on (first + 0.0001, inf), sees the same roots
+            double tq[6], first = inf, second = inf;
+#pragma unroll
+            for (int32_t q = 0; q < 6; ++q) {
+                tq[q] = q < m.count ? quad_root(quads + 16 * (m.first + q), o, dd, -inf, inf) : -1.0;
+                if (tq[q] >= 0.0 && tq[q] <= first) first = tq[q];
             }
             if (first < inf) {
-                for (int32_t q = 0; q < m.count; ++q) {
-                    const double t = quad_root(sc.quads + 16 * (m.first + q), ray.o, dd, first + 0.0001, inf);
-                    if (t >= 0.0 && t <= second) second = t;
-                }
+#pragma unroll
+                for (int32_t q = 0; q < 6; ++q)
+                    if (tq[q] >= first + 0.0001 && tq[q] <= second) second = tq[q];
                 if (second < inf) sp.t_in[k] = first, sp.t_out[k] = second;
             }
         }
     }
+    *out = sp;
 }
+__device__ __forceinline__ void media_spans(const DevScene& sc, const Ray& ray, MediaSpans& sp) {
+    media_spans_impl(sc.media, sc.n_media, sc.spheres, sc.quads, ray.o, d3(ray.d), &sp);
+}
+// The free path -ln(U)/density takes the hardware's f32 logarithm of the 24-bit uniform (the oracle's is f64:
+// the two decide differently only when the free path equals the span to ~1e-7).
 __device__ __forceinline__ void media_sample(const DevScene& sc, const Ray& ray, float tmin, Rng& rng, Closest& best,
                                              const MediaSpans& sp) {
-    const D3 dd = d3(ray.d);
     const double inf = (double)__builtin_inff();
 #pragma unroll
     for (uint32_t k = 0; k < kMaxMedia; ++k) {
@@ -552,14 +563,75 @@ __device__ __forceinline__ void media_sample(const DevScene& sc, const Ray& ray,
         const double t_out = fmin(sp.t_out[k], t_best);
         if (!(t_in < t_out)) continue;
         t_in = fmax(t_in, 0.0);
-        const double len = sqrt64(dot(dd, dd));
-        const double inside = (t_out - t_in) * len;
-        const double hit_distance = sc.media[k].neg_inv_density * log((double)rng_u01(rng));
+        const double inside = (t_out - t_in) * sp.len;
+        const double hit_distance = sc.media[k].neg_inv_density * (double)__logf(rng_u01(rng));
         if (hit_distance > inside) continue;
-        const double t = t_in + hit_distance * rcp64(len);
+        const double t = t_in + hit_distance * sp.inv_len;
         best.h.t = (float)t, best.h.slot = kMediumSlot - (int)k, best.rank = -1, best.meta = 0u;
         hit_set_t64(best.h, t);
     }
+}
+
+// The further attempts of a ray whose surface hit is a light (Q1, see shade_bounce): every attempt draws the free
+// paths of the media the ray crosses in front of the light, and as long as none of them scatters the attempt is
+// those draws and nothing else.  Returns true when the depth ran out that way (the light then emits); false when
+// an attempt scatters: `rng` is back at that attempt's first draw and `depth` counts the attempts before it, so
+// that media_sample repeats the attempt and finds the scatter.  Same draws and same comparisons as media_sample.
+__device__ __attribute__((noinline)) bool media_light_attempts_impl(const DevMedium* media, uint32_t n_media,
+                                                                   const MediaSpans* spans, double t_best, float tmin,
+                                                                   uint64_t* rng_state, uint32_t* depth_io,
+                                                                   uint32_t max_depth) {
+    const MediaSpans sp = *spans;
+    Rng rng;
+    rng.s = *rng_state;
+    uint32_t depth = *depth_io;
+    double inside[kMaxMedia], neg_inv[kMaxMedia];
+    bool any = false;
+#pragma unroll
+    for (uint32_t k = 0; k < kMaxMedia; ++k) {
+        inside[k] = -1.0, neg_inv[k] = 0.0;
+        if (k >= n_media || !(sp.t_out[k] >= sp.t_in[k])) continue;
+        double t_in = fmax(sp.t_in[k], (double)tmin);
+        const double t_out = fmin(sp.t_out[k], t_best);
+        if (!(t_in < t_out)) continue;
+        t_in = fmax(t_in, 0.0);
+        inside[k] = (t_out - t_in) * sp.len;
+        neg_inv[k] = media[k].neg_inv_density;
+        any = true;
+    }
+    bool emits = true;
+    if (!any) {  // no medium in front of the light: the attempts are identical and draw nothing
+        depth = max_depth;
+    } else {
+        while (true) {
+            const Rng attempt = rng;
+            bool scatter = false;
+#pragma unroll
+            for (uint32_t k = 0; k < kMaxMedia; ++k) {
+                if (!(inside[k] >= 0.0)) continue;
+                const double hit_distance = neg_inv[k] * (double)__logf(rng_u01(rng));
+                scatter |= !(hit_distance > inside[k]);
+            }
+            if (scatter) {
+                rng = attempt;
+                emits = false;
+                break;
+            }
+            if (++depth >= max_depth) break;
+        }
+    }
+    *rng_state = rng.s, *depth_io = depth;
+    return emits;
+}
+__device__ __forceinline__ bool media_light_attempts(const DevScene& sc, const MediaSpans& sp, const Closest& surface,
+                                                     float tmin, Rng& rng, uint32_t& depth, uint32_t max_depth) {
+    const double t_best = surface.h.slot >= 0 && (surface.meta & kMetaTypeMask) == 1u ? (double)surface.h.t
+                                                                                      : hit_get_t64(surface.h);
+    uint64_t state = rng.s;
+    uint32_t d = depth;
+    const bool emits = media_light_attempts_impl(sc.media, sc.n_media, &sp, t_best, tmin, &state, &d, max_depth);
+    rng.s = state, depth = d;
+    return emits;
 }
 
 // ---- textures (EXT builds): Texture::color_at, material.rs:212-221
@@ -632,12 +704,13 @@ __device__ __forceinline__ F3 texture_color(const DevScene& sc, int mat, F3 albe
 template <bool DIRECT, bool EXT = false>
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* recs, Ray& ray, const HitRec& hit,
                                              uint32_t meta, float tmin, Rng& rng, F3& thr, F3& lsum, uint32_t& depth,
-                                             uint32_t max_depth, bool* retrace = nullptr) {
+                                             uint32_t max_depth, bool* retrace = nullptr, F3* emitted = nullptr) {
     // `retrace` (scenes with constant media): a hit that does not scatter (a light, an absorbed metal reflection)
     // makes the reference trace the SAME ray again, one depth unit per attempt (Q1) — and every attempt draws the
     // media's free paths anew, so the ray may scatter in a medium instead.  With `retrace` given, such a hit
     // returns with *retrace set and the ray unchanged, and the caller evaluates the media again; without media
     // the attempts are identical, so the light ends the path at once and the metal re-samples its fuzz in place.
+    // A light also reports what it emits (*emitted): its further attempts need no second look at the surface.
     if (hit.slot == -1) {  // escaped: (0, background), scene/mod.rs:122
         lsum = lsum + thr * f3(sc.background);
         return false;
@@ -703,6 +776,7 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
     if (kind == 3) {  // DiffuseLight: emits on both faces, never scatters (material.rs:66-72, 94)
         if (EXT && retrace && ++depth < max_depth) {
             *retrace = true;
+            if (emitted) *emitted = albedo;
             return true;
         }
         lsum = lsum + thr * albedo;

@@ -151,13 +151,21 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
                     const Closest surface = best;
                     MediaSpans spans;
                     media_spans(sc, ray, spans);
-                    bool again;
+                    bool again, light = false;
+                    F3 emitted = {0.f, 0.f, 0.f};
                     do {
                         again = false;
                         best = surface;
+                        // the same light again and again (Q1) until a medium scatters or the depth runs out
+                        if (light && media_light_attempts(sc, spans, surface, 0.001f, rng, depth, rp.max_depth)) {
+                            lsum = lsum + thr * emitted;
+                            alive = false;
+                            break;
+                        }
                         media_sample(sc, ray, 0.001f, rng, best, spans);
                         alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
-                                                          rp.max_depth, &again);
+                                                          rp.max_depth, &again, &emitted);
+                        light = again && best.h.slot > kMediumSlot && (emitted.x != 0.f || emitted.y != 0.f || emitted.z != 0.f);
                     } while (again && alive);
                 } else {
                     alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
