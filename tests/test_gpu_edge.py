@@ -131,6 +131,24 @@ def test_4k_frame_and_eight_strata_slices(ra):
     s.close()
 
 
+def test_very_high_sample_counts_per_pixel(ra):
+    """sn >= 1600 leaves the multiply-high stratum split for a division (sn^3 no longer fits 32 bits), and the
+    hand-out then runs to 250 000 chunks per tile: the image must be the same estimate as at sn = 1500, and a
+    strata slice of it must hold its share of the samples."""
+    s = ra.Scene(ra.load_scene(scene_path("quads"), 1.0), 0)
+    a, sa = s.render(8, 8, 1500)
+    b, sb = s.render(8, 8, 2000)
+    assert sa.samples == 64 * 1500 * 1500 and sb.samples == 64 * 2000 * 2000
+    ma, mb = a.astype(np.float64) / 1500 ** 2, b.astype(np.float64) / 2000 ** 2
+    assert np.isfinite(mb).all()
+    assert np.abs(ma - mb).max() <= 0.01 * max(ma.max(), 1e-6)  # ~2e6 samples per pixel on both sides
+    c, sc = s.render(8, 8, 2000, stratum_begin=3, stratum_step=8)
+    assert sc.samples == 64 * (2000 * 2000 // 8)
+    mc = c.astype(np.float64) / (2000 * 2000 // 8)
+    assert np.abs(mc - mb).max() <= 0.02 * max(mb.max(), 1e-6)
+    s.close()
+
+
 def test_library_before_torch_shares_one_hip_runtime():
     """A fresh process that loads librt_amd.so first and imports torch afterwards must still see the GPU from
     torch (api._share_torch_hip_runtime): two HIP runtimes in one process leave torch without devices."""
