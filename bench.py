@@ -81,13 +81,14 @@ class FramePipeline:
             self._finish((self.i + j) % n)
 
 
-def handout_groups(strata: int) -> int:
+def handout_groups(strata: int, tail_chunks: int = 4) -> int:
     """Chunks per tile of the persistent kernel's guided hand-out (render_persistent.hip: phases of 16, 8, 4 and
-    2 strata; a phase leaves four of its chunks' worth, at most half of the rest, to the finer ones)."""
+    2 strata; a phase leaves four of its chunks' worth — one in scenes without a tree —, at most half of the
+    rest, to the finer ones)."""
     done = groups = 0
     for p in range(4):
         per, left = max(2, 16 >> p), strata - done
-        take = left if p == 3 else (left - min(left // 2, 4 * per)) // per * per
+        take = left if p == 3 else (left - min(left // 2, tail_chunks * per)) // per * per
         groups += (take + per - 1) // per
         done += take
     return groups
@@ -250,7 +251,7 @@ def main() -> None:
         hbm_bytes = 12.0 * w * h + 12.0 * my_samples + 216.0 * seg_per_sample * my_samples
     else:
         tiles = ((w + 7) // 8) * ((h + 7) // 8)
-        hbm_bytes = 36.0 * w * h + 768.0 * tiles * handout_groups(my_samples // (w * h))
+        hbm_bytes = 36.0 * w * h + 768.0 * tiles * handout_groups(my_samples // (w * h), 4 if info.render_nodes else 1)
 
     if rank == 0:
         workload = (f"scenes/{args.scene}.yaml {w}x{h} {sn * sn} spp, max_depth 40, "

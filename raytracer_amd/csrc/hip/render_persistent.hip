@@ -346,7 +346,9 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
         rp.stratum_begin >= rp.n_strata ? 0 : (rp.n_strata - rp.stratum_begin + rp.stratum_step - 1) / rp.stratum_step;
     // A phase leaves kTailChunks of its own chunks' worth of strata to the finer phases after it (a heavy chunk
     // takes several times the mean), but never more than half of what is left; the last phase takes the rest.
-    const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K"))) : 4u;
+    // Without a tree the chunks cost much the same and the samples are cheap (40-50 Gsamples/s): there the small
+    // chunks' own overhead shows, and one chunk's worth per phase is enough.
+    const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K"))) : (sc.has_tree ? 4u : 1u);
     const uint32_t first_chunk = kChunkStrata;
     uint32_t done = 0, groups = 0;
     for (int p = 0; p < kPhases; ++p) {
