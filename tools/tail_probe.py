@@ -11,4 +11,4 @@ for name in sys.argv[1:]:
         out.append(f"1/{step}: {ms:7.2f} ms {1920*1080*1024/step/ms/1e3:6.0f} Ms/s")
     ms = min(s.render(1920, 1080, 8)[1].kernel_ms for _ in range(3))
     out.append(f"64spp: {ms:6.2f} ms")
-    print(name, os.environ.get("RT_NO_HEAVY_FIRST", "-"), " | ".join(out), flush=True)
+    print(name, os.environ.get("RT_TAIL_K", "-"), " | ".join(out), flush=True)
