@@ -33,6 +33,7 @@ struct DevMedium {
     double neg_inv_density;  // -(1 / d), surfaces.rs:605
     double pad;
 };
+static_assert(sizeof(DevMedium) == 32, "media_spans_impl reads DevMedium as eight 32-bit words");
 constexpr uint32_t kMaxMedia = 4;
 constexpr int kMediumSlot = -100;  // hit slot of medium k is kMediumSlot - k (loose primitives use -2 .. -17)
 
