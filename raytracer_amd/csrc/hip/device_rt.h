@@ -520,6 +520,10 @@ __device__ __forceinline__ uintptr_t uniform_address(const void* p) {
 // The media and their boundaries are the same for every lane: scalar loads, not two dozen dependent vector round
 // trips per ray (media_spans took 46 000 cycles of a cornell-smoke shade trip with those, 9 500 without).
 typedef const int32_t __attribute__((address_space(4)))* UniformI32;
+// -(1 / density) of medium k through a scalar load; `media` must be a wave-uniform address
+__device__ __forceinline__ double medium_neg_inv_density(uintptr_t media, uint32_t k) {
+    return ((UniformF64)(media + 32u * k))[2];
+}
 __device__ __attribute__((noinline)) void media_spans_impl(const DevMedium* media_g, uint32_t n_media, const double* spheres_g,
                                                            const double* quads_g, D3 o, D3 dd, MediaSpans* out) {
     const UniformI32 media = (UniformI32)uniform_address(media_g);  // DevMedium: boundary first count material | f64 f64
@@ -580,7 +584,7 @@ __device__ __forceinline__ void media_sample(const DevScene& sc, const Ray& ray,
         if (!(t_in < t_out)) continue;
         t_in = fmax(t_in, 0.0);
         const double inside = (t_out - t_in) * sp.len;
-        const double hit_distance = sc.media[k].neg_inv_density * (double)__logf(rng_u01(rng));
+        const double hit_distance = medium_neg_inv_density((uintptr_t)sc.media, k) * (double)__logf(rng_u01(rng));
         if (hit_distance > inside) continue;
         const double t = t_in + hit_distance * sp.inv_len;
         best.h.t = (float)t, best.h.slot = kMediumSlot - (int)k, best.rank = -1, best.meta = 0u;
@@ -612,7 +616,7 @@ __device__ __attribute__((noinline)) bool media_light_attempts_impl(const DevMed
         if (!(t_in < t_out)) continue;
         t_in = fmax(t_in, 0.0);
         inside[k] = (t_out - t_in) * sp.len;
-        neg_inv[k] = media[k].neg_inv_density;
+        neg_inv[k] = medium_neg_inv_density(uniform_address(media), k);
         any = true;
     }
     bool emits = true;
