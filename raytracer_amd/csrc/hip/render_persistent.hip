@@ -64,7 +64,7 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int STACK, bool STATS, bool DIRECT, bool EXT>
+template <int STACK, bool STATS, bool DIRECT, bool EXT, bool MEDIA>
 __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             // ---- shade the finished segment (scene/mod.rs:104-123)
             if (mine && alive) {
                 F3 lsum = {0.f, 0.f, 0.f};  // a path contributes once, where it ends
-                if (EXT && sc.n_media) {
+                if (MEDIA) {
                     // the media are evaluated after the surface trace, and again on every re-trace of a ray whose
                     // hit did not scatter (see shade_bounce)
                     const Closest surface = best;
@@ -313,12 +313,16 @@ __global__ void resolve_kernel(const float* __restrict__ acc, uint32_t width, ui
 template <int STACK, bool STATS, bool DIRECT>
 static void launch_one(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
                        float* d_acc, DevCounters* counters, uint32_t* work_counter, hipStream_t stream) {
-    // scenes with textures or moving spheres run the EXT build; the others keep the lean one
-    if (sc.ext)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true>), dim3(blocks), dim3(kBlock), 0, stream,
+    // scenes with textures or moving spheres run the EXT build, those with constant media the EXT + MEDIA one; the
+    // others keep the lean one (each feature costs registers in every stage, used or not)
+    if (sc.ext && sc.n_media)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, true>), dim3(blocks), dim3(kBlock), 0, stream,
+                           sc, rp, plan, d_acc, counters, work_counter);
+    else if (sc.ext)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
     else
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false>), dim3(blocks), dim3(kBlock), 0, stream,
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
 }
 
