@@ -296,6 +296,9 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     Bvh& rb = s.render_bvh;
     const size_t n_tree = tree_ids.size();
     s.has_tree = n_tree > 0;
+    s.dev.tree_tris_only = 1u;
+    for (int32_t id : tree_ids)
+        if (d.surfaces[id].type != RT_SURF_TRIANGLE) s.dev.tree_tris_only = 0u;
     const FlatTree ft(rb);
     const size_t n_slots = n_tree + ((s.has_tree && ft.root_is_leaf) ? 1 : 0);
 

@@ -399,14 +399,15 @@ __device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, f
 }
 
 // One leaf slot whose record (p0 p1 p2) is in registers.  Returns true when it was the last slot of its leaf.
-template <bool STATS, bool EXT = false>
+template <bool STATS, bool EXT = false, bool TRIS = false>
 __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           float4 p0, float4 p1, float4 p2, Closest& best, TraceStats& st) {
     const uint32_t meta = __float_as_uint(p0.w);
     const uint32_t type = meta & kMetaTypeMask;
     float t = -1.f, bu = 0.f, bv = 0.f;
     double t64 = -1.0;
-    if (type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
+    // TRIS: the host found nothing but triangles in the render tree (every mesh scene): no sphere / quad code here
+    if (TRIS || type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
         if (STATS) st.tris++;
         const F3 e1 = f3(p1), e2 = f3(p2);
         const F3 pvec = cross(ray.d, e2);
@@ -440,29 +441,29 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
         const int rank = __float_as_int(p1.w);
         if (t < best.h.t || rank > best.rank) {
             best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank, best.meta = meta;
-            if (type != 1u) hit_set_t64(best.h, t64);
+            if (!TRIS && type != 1u) hit_set_t64(best.h, t64);
         }
     }
     return (meta & kMetaLast) != 0u;
 }
-template <bool STATS, bool EXT = false>
+template <bool STATS, bool EXT = false, bool TRIS = false>
 __device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           Closest& best, TraceStats& st) {
-    return prim_test<STATS, EXT>(sc, ray, r, tmin, slot, sc.prims[3 * slot], sc.prims[3 * slot + 1], sc.prims[3 * slot + 2], best,
+    return prim_test<STATS, EXT, TRIS>(sc, ray, r, tmin, slot, sc.prims[3 * slot], sc.prims[3 * slot + 1], sc.prims[3 * slot + 2], best,
                             st);
 }
 // A whole leaf.  The records of its first two slots are fetched together (render-tree leaves hold at most two
 // in all but degenerate cases; the array is padded by one slot), so a two-triangle leaf costs one memory
 // round trip, not two.
-template <bool STATS, bool EXT = false>
+template <bool STATS, bool EXT = false, bool TRIS = false>
 __device__ __forceinline__ void leaf_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           Closest& best, TraceStats& st) {
     const float4 a0 = sc.prims[3 * slot + 0], a1 = sc.prims[3 * slot + 1], a2 = sc.prims[3 * slot + 2];
     const float4 b0 = sc.prims[3 * slot + 3], b1 = sc.prims[3 * slot + 4], b2 = sc.prims[3 * slot + 5];
-    if (prim_test<STATS, EXT>(sc, ray, r, tmin, slot, a0, a1, a2, best, st)) return;
-    if (prim_test<STATS, EXT>(sc, ray, r, tmin, slot + 1, b0, b1, b2, best, st)) return;
+    if (prim_test<STATS, EXT, TRIS>(sc, ray, r, tmin, slot, a0, a1, a2, best, st)) return;
+    if (prim_test<STATS, EXT, TRIS>(sc, ray, r, tmin, slot + 1, b0, b1, b2, best, st)) return;
     slot += 2;
-    while (!prim_step<STATS, EXT>(sc, ray, r, tmin, slot, best, st)) ++slot;
+    while (!prim_step<STATS, EXT, TRIS>(sc, ray, r, tmin, slot, best, st)) ++slot;
 }
 
 // The classic while-while loop over the steps (used by wf_extend and the f32 AOV kernel).

@@ -64,8 +64,8 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int STACK, bool STATS, bool DIRECT, bool EXT, bool MEDIA>
-__global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+template <int STACK, bool STATS, bool DIRECT, bool EXT, bool MEDIA, bool TRIS>
+__global__ __launch_bounds__(kBlock, (TRIS && !EXT) ? 5 : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock, RT_MIN_WAVES) void render_persistent_kernel
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
             if (node < 0) {
-                leaf_step<STATS, EXT>(sc, ray, sr, 0.001f, ~node, best, st);
+                leaf_step<STATS, EXT, TRIS>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = stack_pop(stack, kBlock, sp);
             }
         } else {
@@ -316,14 +316,17 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
     // scenes with textures or moving spheres run the EXT build, those with constant media the EXT + MEDIA one; the
     // others keep the lean one (each feature costs registers in every stage, used or not)
     if (sc.ext && sc.n_media)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, true>), dim3(blocks), dim3(kBlock), 0, stream,
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, true, false>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
     else if (sc.ext)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false>), dim3(blocks), dim3(kBlock), 0, stream,
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false, false>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
+    else if (sc.tree_tris_only)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, true>), dim3(blocks), dim3(kBlock), 0,
+                           stream, sc, rp, plan, d_acc, counters, work_counter);
     else
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false>), dim3(blocks), dim3(kBlock), 0, stream,
-                           sc, rp, plan, d_acc, counters, work_counter);
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, false>), dim3(blocks), dim3(kBlock), 0,
+                           stream, sc, rp, plan, d_acc, counters, work_counter);
 }
 
 template <int STACK>
@@ -343,7 +346,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
                                     uint32_t* work_counter, bool stats, hipStream_t stream) {
     PersistentPlan plan;
     plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T")) : 40;
-    plan.node_bias = getenv("RT_NODE_BIAS") ? atoi(getenv("RT_NODE_BIAS")) : 3;
+    plan.node_bias = getenv("RT_NODE_BIAS") ? atoi(getenv("RT_NODE_BIAS")) : 2;
     plan.tiles_x = (rp.width + 7u) >> 3;
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
     plan.my_strata =
