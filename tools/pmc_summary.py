@@ -15,12 +15,14 @@ for k, c in tot.items():
         print(f"   {name:36s} {c[name]:.6g}")
 
 # Derived figures for the render kernel (one launch per pass; counters summed over all XCDs / SEs / CUs).
-# SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count in units of 4 clocks; a wave is resident on one SIMD, four per SIMD
-# at this kernel's occupancy, so SIMD-time = SQ_WAVE_CYCLES / 4.
+# SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count in units of 4 clocks; a wave is resident on one SIMD, WAVES_PER_SIMD
+# of them at this kernel's occupancy (argv[2], default 5: the triangles-only build), so
+# SIMD-time = SQ_WAVE_CYCLES / WAVES_PER_SIMD.
+WAVES_PER_SIMD = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
 for k, c in tot.items():
     if "render_persistent_kernel" not in k or c.get("SQ_INSTS_VALU", 0) < 1e9:
         continue
-    simd_time = c["SQ_WAVE_CYCLES"] / 4.0
+    simd_time = c["SQ_WAVE_CYCLES"] / WAVES_PER_SIMD
     print(f"== derived: {k}")
     print(f"   VALU busy (SQ_ACTIVE_INST_VALU / SIMD-time)         {c['SQ_ACTIVE_INST_VALU'] / simd_time:.3f}")
     print(f"   lane utilisation (THREAD_CYCLES_VALU / 64 / INSTS)  {c['SQ_THREAD_CYCLES_VALU'] / 64.0 / c['SQ_INSTS_VALU']:.3f}")
