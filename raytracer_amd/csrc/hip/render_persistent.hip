@@ -378,7 +378,9 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // harmless (they start when a slot frees up and find the counter exhausted).
     const uint32_t blocks = std::min<uint32_t>(n_cus * 8u, (plan.n_chunks + 3u) / 4u);
     // near-first traversal keeps at most (depth - 1) deferred children
+    // (LDS per block: 24 levels -> 5 blocks per CU, 32 -> 4, 40 -> 3, 56 -> 2)
     if (tree_depth <= 24) e = launch_stack<24>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
+    else if (tree_depth <= 32) e = launch_stack<32>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     else if (tree_depth <= 40) e = launch_stack<40>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     else if (tree_depth <= 56) e = launch_stack<56>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     else return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"

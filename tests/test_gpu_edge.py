@@ -40,13 +40,14 @@ def test_spheres_and_quads_inside_the_render_tree(ra, ref, tmp_path):
     scene.close()
 
 
-@pytest.mark.parametrize("n,min_depth", [(120, 25), (3000, 41)])
-def test_deep_render_trees(ra, ref, tmp_path, n, min_depth):
-    """Depth 28 runs the 40-level stack build, depth 43 the 56-level one (and makes the pool kernel fall back)."""
+@pytest.mark.parametrize("n,min_depth,max_depth", [(120, 25, 32), (300, 33, 40), (3000, 41, 56)])
+def test_deep_render_trees(ra, ref, tmp_path, n, min_depth, max_depth):
+    """Depth 28 runs the 32-level stack build, depth 38 the 40-level one, depth 43 the 56-level one (which also makes
+    the pool kernel fall back)."""
     path = synth.deep_tree(tmp_path, n, 0.5)
     w, h, sn = 96, 64, 3
     scene = ra.Scene(ra.load_scene(path, w / h), 0)
-    assert min_depth <= scene.info().render_depth <= 56
+    assert min_depth <= scene.info().render_depth <= max_depth
     oracle = ref.RefScene.from_yaml(path, w / h)
     _primary_parity(scene, oracle, w, h)
     want, _ = oracle.render(w, h, sn, threads=16, sampler=1)
