@@ -296,9 +296,12 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     Bvh& rb = s.render_bvh;
     const size_t n_tree = tree_ids.size();
     s.has_tree = n_tree > 0;
-    s.dev.tree_tris_only = 1u;
-    for (int32_t id : tree_ids)
-        if (d.surfaces[id].type != RT_SURF_TRIANGLE) s.dev.tree_tris_only = 0u;
+    bool only_tris = true, only_spheres = true;
+    for (int32_t id : tree_ids) {
+        only_tris = only_tris && d.surfaces[id].type == RT_SURF_TRIANGLE;
+        only_spheres = only_spheres && d.surfaces[id].type == RT_SURF_SPHERE;
+    }
+    s.dev.tree_kind = only_tris ? 1u : (only_spheres ? 2u : 0u);
     const FlatTree ft(rb);
     const size_t n_slots = n_tree + ((s.has_tree && ft.root_is_leaf) ? 1 : 0);
 

@@ -399,15 +399,16 @@ __device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, f
 }
 
 // One leaf slot whose record (p0 p1 p2) is in registers.  Returns true when it was the last slot of its leaf.
-template <bool STATS, bool EXT = false, bool TRIS = false>
+template <bool STATS, bool EXT = false, int TREE = 0>
 __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           float4 p0, float4 p1, float4 p2, Closest& best, TraceStats& st) {
     const uint32_t meta = __float_as_uint(p0.w);
     const uint32_t type = meta & kMetaTypeMask;
     float t = -1.f, bu = 0.f, bv = 0.f;
     double t64 = -1.0;
-    // TRIS: the host found nothing but triangles in the render tree (every mesh scene): no sphere / quad code here
-    if (TRIS || type == 1u) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
+    // TREE: what the host found in the render tree — 1: nothing but triangles (every mesh scene), 2: nothing but
+    // spheres (one-weekend), 0: a mix.  The tests that cannot occur are not compiled in: each costs registers.
+    if (TREE == 1 || (TREE == 0 && type == 1u)) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
         if (STATS) st.tris++;
         const F3 e1 = f3(p1), e2 = f3(p2);
         const F3 pvec = cross(ray.d, e2);
@@ -425,7 +426,7 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
                 }
             }
         }
-    } else if (type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
+    } else if (TREE == 2 || type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
         if (STATS) st.spheres++;
         const uint32_t si = meta >> kMetaIndexShift;
         t64 = sphere_root_gated<EXT>(sc.spheres + 4 * si, sc.sphere_gate + 6 * si, sc.sphere_end + 3 * si, ray.time, ray.o,
@@ -441,29 +442,33 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
         const int rank = __float_as_int(p1.w);
         if (t < best.h.t || rank > best.rank) {
             best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank, best.meta = meta;
-            if (!TRIS && type != 1u) hit_set_t64(best.h, t64);
+            if (TREE != 1 && type != 1u) hit_set_t64(best.h, t64);
         }
     }
     return (meta & kMetaLast) != 0u;
 }
-template <bool STATS, bool EXT = false, bool TRIS = false>
+template <bool STATS, bool EXT = false, int TREE = 0>
 __device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           Closest& best, TraceStats& st) {
-    return prim_test<STATS, EXT, TRIS>(sc, ray, r, tmin, slot, sc.prims[3 * slot], sc.prims[3 * slot + 1], sc.prims[3 * slot + 2], best,
+    return prim_test<STATS, EXT, TREE>(sc, ray, r, tmin, slot, sc.prims[3 * slot], sc.prims[3 * slot + 1], sc.prims[3 * slot + 2], best,
                             st);
 }
 // A whole leaf.  The records of its first two slots are fetched together (render-tree leaves hold at most two
 // in all but degenerate cases; the array is padded by one slot), so a two-triangle leaf costs one memory
 // round trip, not two.
-template <bool STATS, bool EXT = false, bool TRIS = false>
+template <bool STATS, bool EXT = false, int TREE = 0>
 __device__ __forceinline__ void leaf_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           Closest& best, TraceStats& st) {
+    if (TREE == 2) {  // spheres fetch their own data by index: one copy of the test, slot by slot
+        while (!prim_step<STATS, EXT, TREE>(sc, ray, r, tmin, slot, best, st)) ++slot;
+        return;
+    }
     const float4 a0 = sc.prims[3 * slot + 0], a1 = sc.prims[3 * slot + 1], a2 = sc.prims[3 * slot + 2];
     const float4 b0 = sc.prims[3 * slot + 3], b1 = sc.prims[3 * slot + 4], b2 = sc.prims[3 * slot + 5];
-    if (prim_test<STATS, EXT, TRIS>(sc, ray, r, tmin, slot, a0, a1, a2, best, st)) return;
-    if (prim_test<STATS, EXT, TRIS>(sc, ray, r, tmin, slot + 1, b0, b1, b2, best, st)) return;
+    if (prim_test<STATS, EXT, TREE>(sc, ray, r, tmin, slot, a0, a1, a2, best, st)) return;
+    if (prim_test<STATS, EXT, TREE>(sc, ray, r, tmin, slot + 1, b0, b1, b2, best, st)) return;
     slot += 2;
-    while (!prim_step<STATS, EXT, TRIS>(sc, ray, r, tmin, slot, best, st)) ++slot;
+    while (!prim_step<STATS, EXT, TREE>(sc, ray, r, tmin, slot, best, st)) ++slot;
 }
 
 // The classic while-while loop over the steps (used by wf_extend and the f32 AOV kernel).

@@ -64,8 +64,8 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int STACK, bool STATS, bool DIRECT, bool EXT, bool MEDIA, bool TRIS>
-__global__ __launch_bounds__(kBlock, (TRIS && !EXT) ? 5 : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+template <int STACK, bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE>
+__global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock, (TRIS && !EXT) ? 5 : RT_MIN_WAVES) void ren
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
             if (node < 0) {
-                leaf_step<STATS, EXT, TRIS>(sc, ray, sr, 0.001f, ~node, best, st);
+                leaf_step<STATS, EXT, TREE>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = stack_pop(stack, kBlock, sp);
             }
         } else {
@@ -316,16 +316,19 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
     // scenes with textures or moving spheres run the EXT build, those with constant media the EXT + MEDIA one; the
     // others keep the lean one (each feature costs registers in every stage, used or not)
     if (sc.ext && sc.n_media)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, true, false>), dim3(blocks), dim3(kBlock), 0, stream,
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, true, 0>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
     else if (sc.ext)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false, false>), dim3(blocks), dim3(kBlock), 0, stream,
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false, 0>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
-    else if (sc.tree_tris_only)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, true>), dim3(blocks), dim3(kBlock), 0,
+    else if (sc.tree_kind == 1u)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 1>), dim3(blocks), dim3(kBlock), 0,
+                           stream, sc, rp, plan, d_acc, counters, work_counter);
+    else if (sc.tree_kind == 2u)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 2>), dim3(blocks), dim3(kBlock), 0,
                            stream, sc, rp, plan, d_acc, counters, work_counter);
     else
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, false>), dim3(blocks), dim3(kBlock), 0,
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 0>), dim3(blocks), dim3(kBlock), 0,
                            stream, sc, rp, plan, d_acc, counters, work_counter);
 }
 
