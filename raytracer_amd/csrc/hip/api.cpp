@@ -296,12 +296,13 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     Bvh& rb = s.render_bvh;
     const size_t n_tree = tree_ids.size();
     s.has_tree = n_tree > 0;
-    bool only_tris = true, only_spheres = true;
+    bool only_tris = true, only_spheres = true, only_quads = true;
     for (int32_t id : tree_ids) {
         only_tris = only_tris && d.surfaces[id].type == RT_SURF_TRIANGLE;
         only_spheres = only_spheres && d.surfaces[id].type == RT_SURF_SPHERE;
+        only_quads = only_quads && d.surfaces[id].type == RT_SURF_QUAD;
     }
-    s.dev.tree_kind = only_tris ? 1u : (only_spheres ? 2u : 0u);
+    s.dev.tree_kind = only_tris ? 1u : (only_spheres ? 2u : (only_quads ? 3u : 0u));
     const FlatTree ft(rb);
     const size_t n_slots = n_tree + ((s.has_tree && ft.root_is_leaf) ? 1 : 0);
 

@@ -407,7 +407,8 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
     float t = -1.f, bu = 0.f, bv = 0.f;
     double t64 = -1.0;
     // TREE: what the host found in the render tree — 1: nothing but triangles (every mesh scene), 2: nothing but
-    // spheres (one-weekend), 0: a mix.  The tests that cannot occur are not compiled in: each costs registers.
+    // spheres (one-weekend), 3: nothing but quads (the cornell example), 0: a mix.  The tests that cannot occur are
+    // not compiled in: each costs registers.
     if (TREE == 1 || (TREE == 0 && type == 1u)) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
         if (STATS) st.tris++;
         const F3 e1 = f3(p1), e2 = f3(p2);
@@ -426,7 +427,7 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
                 }
             }
         }
-    } else if (TREE == 2 || type == 0u) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
+    } else if (TREE == 2 || (TREE == 0 && type == 0u)) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
         if (STATS) st.spheres++;
         const uint32_t si = meta >> kMetaIndexShift;
         t64 = sphere_root_gated<EXT>(sc.spheres + 4 * si, sc.sphere_gate + 6 * si, sc.sphere_end + 3 * si, ray.time, ray.o,
@@ -459,7 +460,7 @@ __device__ __forceinline__ bool prim_step(const DevScene& sc, const Ray& ray, co
 template <bool STATS, bool EXT = false, int TREE = 0>
 __device__ __forceinline__ void leaf_step(const DevScene& sc, const Ray& ray, const SlabRay& r, float tmin, int slot,
                                           Closest& best, TraceStats& st) {
-    if (TREE == 2) {  // spheres fetch their own data by index: one copy of the test, slot by slot
+    if (TREE >= 2) {  // spheres and quads fetch their own data by index: one copy of the test, slot by slot
         while (!prim_step<STATS, EXT, TREE>(sc, ray, r, tmin, slot, best, st)) ++slot;
         return;
     }

@@ -71,7 +71,7 @@ struct DevScene {
     const int32_t* quad_mat;    // material id per quad
     // textures and moving spheres (the EXT builds of the kernels; `ext` == 0 means none are present)
     uint32_t ext;
-    uint32_t tree_kind;         // what the render tree holds: 1 triangles only, 2 spheres only, 0 a mix
+    uint32_t tree_kind;         // what the render tree holds: 1 triangles only, 2 spheres only, 3 quads only, 0 a mix
     uint32_t n_media;
     const DevMedium* media;
     const double* sphere_end;   // 3 per sphere: centre at ray time 1 (Sphere::moving, surfaces.rs:43-54)

@@ -318,6 +318,9 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
     if (sc.ext && sc.n_media)
         hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, true, 0>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
+    else if (sc.ext && sc.tree_kind == 2u)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false, 2>), dim3(blocks), dim3(kBlock), 0, stream,
+                           sc, rp, plan, d_acc, counters, work_counter);
     else if (sc.ext)
         hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false, 0>), dim3(blocks), dim3(kBlock), 0, stream,
                            sc, rp, plan, d_acc, counters, work_counter);
@@ -326,6 +329,9 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
                            stream, sc, rp, plan, d_acc, counters, work_counter);
     else if (sc.tree_kind == 2u)
         hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 2>), dim3(blocks), dim3(kBlock), 0,
+                           stream, sc, rp, plan, d_acc, counters, work_counter);
+    else if (sc.tree_kind == 3u)
+        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 3>), dim3(blocks), dim3(kBlock), 0,
                            stream, sc, rp, plan, d_acc, counters, work_counter);
     else
         hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 0>), dim3(blocks), dim3(kBlock), 0,
