@@ -40,6 +40,25 @@ def test_spheres_and_quads_inside_the_render_tree(ra, ref, tmp_path):
     scene.close()
 
 
+def test_spheres_only_render_tree(ra, ref, tmp_path):
+    """A tree of nothing but spheres — with the hollow glass ball: a negative radius behind its leaf's gate, Q8 —
+    runs a build of its own (TREE = 2), like the triangles-only mesh scenes (the quads-only one is the cornell
+    example's, tests/test_examples.py)."""
+    path = synth.many_prims(tmp_path, n_spheres=28, n_quads=0, with_mesh=False)
+    w, h, sn = 120, 80, 4
+    scene = ra.Scene(ra.load_scene(path, w / h), 0)
+    info = scene.info()
+    assert info.n_surfaces == 31 and info.n_loose == 0
+    oracle = ref.RefScene.from_yaml(path, w / h)
+    _primary_parity(scene, oracle, w, h)
+    for sampler in (0, 1):
+        want, _ = oracle.render(w, h, sn, threads=16, sampler=sampler)
+        img, st = scene.render(w, h, sn, sampler=sampler, collect_stats=True)
+        _check_image(img, want, sn * sn, f"spheres only, sampler {sampler}")
+        assert st.tri_tests == 0 and st.quad_tests == 0 and st.sphere_tests > 0
+    scene.close()
+
+
 @pytest.mark.parametrize("n,min_depth,max_depth", [(120, 25, 32), (300, 33, 40), (3000, 41, 56)])
 def test_deep_render_trees(ra, ref, tmp_path, n, min_depth, max_depth):
     """Depth 28 runs the 32-level stack build, depth 38 the 40-level one, depth 43 the 56-level one (which also makes
