@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -280,6 +281,10 @@ class SceneDesc:
             self._struct = None
 
     def __del__(self):
+        # at interpreter shutdown the process's memory goes back anyway; do not call into a library whose HIP
+        # runtime may already be unloading
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -326,6 +331,8 @@ class Scene:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():  # see SceneDesc.__del__
+            return
         try:
             self.close()
         except Exception:
