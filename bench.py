@@ -82,13 +82,14 @@ class FramePipeline:
 
 
 def handout_groups(strata: int, tail_chunks: int = 4) -> int:
-    """Chunks per tile of the persistent kernel's guided hand-out (render_persistent.hip: phases of 16, 8, 4 and
-    2 strata; a phase leaves four of its chunks' worth — one in scenes without a tree —, at most half of the
-    rest, to the finer ones)."""
+    """Chunks per tile of the persistent kernel's guided hand-out (render_persistent.hip: five phases of shrinking
+    chunks — 32 strata first for frames of 512 strata and more, else 16, then halving down to 2; a phase leaves
+    four of its chunks' worth — one in scenes without a tree —, at most half of the rest, to the finer ones)."""
+    first = 32 if strata >= 512 else 16
     done = groups = 0
-    for p in range(4):
-        per, left = max(2, 16 >> p), strata - done
-        take = left if p == 3 else (left - min(left // 2, tail_chunks * per)) // per * per
+    for p in range(5):
+        per, left = max(2, first >> p), strata - done
+        take = left if p == 4 else (left - min(left // 2, tail_chunks * per)) // per * per
         groups += (take + per - 1) // per
         done += take
     return groups

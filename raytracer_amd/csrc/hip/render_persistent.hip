@@ -27,20 +27,20 @@ constexpr int kBlock = 256;
 #define RT_MIN_WAVES 4
 #endif
 constexpr uint32_t kChunkStrata = 16;  // strata per chunk in the first phase (a chunk is 64 pixels x this many strata)
-constexpr int kPhases = 4;
+constexpr int kPhases = 5;
 
 struct PersistentPlan {
     int shade_threshold;     // run the shade stage once this many lanes wait in it (or nothing else can run)
     int node_bias;           // node stage runs when n_node * node_bias >= n_leaf * 4
     uint32_t tiles_x, n_tiles;
     uint32_t my_strata;      // strata this call renders (begin, begin+step, ...)
-    // Guided hand-out in kPhases phases of shrinking chunks (16, 8, 4, 2 strata): phase p covers the strata
+    // Guided hand-out in kPhases phases of shrinking chunks (32 or 16, then 16, 8, 4, 2 strata): phase p covers the strata
     // [phase_first[p], phase_first[p + 1]) of every tile in groups [phase_end[p - 1], phase_end[p]).  The waves
     // then run dry within a small chunk's time of each other; with 16-strata chunks throughout, the waves still
     // busy with a heavy chunk when the counter ran out cost 5 ms of a 33 ms launch on lucy.yaml, 13 of 71 on
     // teapot.yaml (1/8 of the 1024 strata, as an 8-GPU run gives each rank).
-    uint32_t phase_first[5], phase_end[4], phase_strata[4];
-    uint32_t n_chunks;       // n_tiles * phase_end[3]
+    uint32_t phase_first[kPhases + 1], phase_end[kPhases], phase_strata[kPhases];
+    uint32_t n_chunks;       // n_tiles * phase_end[kPhases - 1]
 };
 
 // Lane stages, encoded in `node`: an inner node id (>= 0) = one node_step pending; a leaf reference (< 0,
@@ -365,7 +365,8 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // Without a tree the chunks cost much the same and the samples are cheap (40-50 Gsamples/s): there the small
     // chunks' own overhead shows, and one chunk's worth per phase is enough.
     const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K"))) : (sc.has_tree ? 4u : 1u);
-    const uint32_t first_chunk = kChunkStrata;
+    // frames of 512 strata and more start with chunks twice as large (+1 %: fewer flushes, longer stays on a tile)
+    const uint32_t first_chunk = plan.my_strata >= 512u ? 2u * kChunkStrata : kChunkStrata;
     uint32_t done = 0, groups = 0;
     for (int p = 0; p < kPhases; ++p) {
         const uint32_t per = std::max(2u, first_chunk >> p), left = plan.my_strata - done;

@@ -112,7 +112,8 @@ def test_frame_pipeline_single_rank_finishes_in_step():
 def test_handout_groups_matches_the_kernel_plan():
     import bench
 
-    # 1024 strata: 960 in 16s, then 32 in 8s, 16 in 4s, 16 in 2s
-    assert bench.handout_groups(1024) == 60 + 4 + 4 + 8
-    assert bench.handout_groups(128) == 4 + 4 + 4 + 8
+    # 1024 strata: 896 in 32s, then 64 in 16s, 32 in 8s, 16 in 4s, 16 in 2s
+    assert bench.handout_groups(1024) == 28 + 4 + 4 + 4 + 8
+    # 128 strata: 64 in 16s, 32 in 8s, 16 in 4s, 8 in 2s, 8 in 2s
+    assert bench.handout_groups(128) == 4 + 4 + 4 + 4 + 4
     assert bench.handout_groups(4) == 2 and bench.handout_groups(1) == 1 and bench.handout_groups(0) == 0
