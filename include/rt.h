@@ -145,11 +145,11 @@ typedef struct rt_scene_desc {
  * `aspect_ratio`.  *out is owned by the library; release with rt_scene_desc_free. */
 int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_scene_desc** out);
 
-/* Procedural example scenes: replaces Example::from_str + Example::scene (scene/example.rs:53-79) for
- * "one-weekend" (example.rs:84-142; the reference's default when no --scene is given, main.rs:102-106) and
- * "cornell" (example.rs:262-329, its rotated/translated boxes baked into quads).  The other six examples
- * need textures, moving spheres or volumes and return an error naming that.  The reference draws
- * one-weekend from thread_rng(); here `seed` fixes the draws.  Release *out with rt_scene_desc_free. */
+/* Procedural example scenes: replaces Example::from_str + Example::scene (scene/example.rs:53-79) for all
+ * eight names the reference knows (example.rs:53-66): "one-weekend" (the reference's default when no --scene is
+ * given, main.rs:102-106), "random-spheres", "two-spheres", "two-perlin", "earth", "cornell", "cornell-smoke",
+ * "final-scene"; any other name is an error.  The reference draws the random ones from thread_rng(); here `seed`
+ * fixes the draws.  Release *out with rt_scene_desc_free. */
 int rt_example_scene(const char* name, double aspect_ratio, uint64_t seed, int use_bvh, rt_scene_desc** out);
 void rt_scene_desc_free(rt_scene_desc* desc);
 
@@ -221,7 +221,12 @@ typedef struct rt_stats {
 /* Renders into DEVICE memory: d_rgb_sum = 3*width*height floats, row 0 = top row of the image
  * (pj = height - idx/width - 1, main.rs:158), un-normalised radiance SUM over the strata of this
  * call (overwritten, not accumulated).  `stream` is a hipStream_t (NULL = default stream); the call
- * returns after enqueueing unless stats != NULL, in which case it synchronises the stream. */
+ * returns after enqueueing unless stats != NULL, in which case it synchronises the stream.
+ * Scratch (tile accumulator, chunk cursor, counters, events) is kept with the scene in TWO sets used in turn, so
+ * one host thread may keep two renders of one scene in flight on two streams (e.g. double-buffered frames); a
+ * third call re-uses the first set and is ordered after that set's previous use by an event wait on its stream.
+ * The persistent and pool organisations take the sets in turn; the wavefront one has one set of queues and
+ * serialises.  Growing the accumulator for a larger frame (hipFree + hipMalloc) waits for the set's last use. */
 int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream,
                      rt_stats* stats);
 

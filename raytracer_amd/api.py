@@ -299,7 +299,7 @@ def load_scene(path: str, aspect_ratio: float, use_bvh: bool = True) -> SceneDes
 
 
 def example_scene(name: str, aspect_ratio: float, seed: int = 0x5EED5EED, use_bvh: bool = True) -> SceneDesc:
-    """Example::scene — scene/example.rs:69-79 ("one-weekend", "cornell")."""
+    """Example::scene — scene/example.rs:53-79 (all eight example names)."""
     out = C.POINTER(RtSceneDesc)()
     _check(lib().rt_example_scene(name.encode(), float(aspect_ratio), int(seed), 1 if use_bvh else 0, C.byref(out)))
     return SceneDesc(out)

@@ -81,11 +81,22 @@ struct rt_scene {
     uint32_t n_cus = 256;
     DevScene dev{};
     std::vector<void*> allocations;
-    DevCounters* d_counters = nullptr;
-    float* d_acc = nullptr;  // persistent kernel's tile-planar accumulator (scratch)
-    size_t acc_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::unique_ptr<WavefrontState> wf;
+    // Scratch of a render call: the persistent kernels' tile-planar accumulator, the counters block (chunk
+    // cursor + statistics) and the timing events.  Two sets, used in turn, so that two renders of one scene can
+    // be in flight on two streams (frame i+1 starts on the CUs that frame i's draining waves leave idle); a call
+    // whose slot was last used on another stream makes its stream wait for that use to end (`done`).
+    struct Slot {
+        DevCounters* d_counters = nullptr;
+        float* d_acc = nullptr;
+        size_t acc_bytes = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
+        hipStream_t last_stream = nullptr;
+        bool used = false;
+    };
+    static constexpr int kSlots = 2;
+    Slot slots[kSlots];
+    int next_slot = 0;
+    std::unique_ptr<WavefrontState> wf;  // its queues are one set: wavefront renders all use slot 0
 
     // flattened host copies (kept for host-only inspection and tests)
     std::vector<float4> nodes, prims, tri_shade, materials;
@@ -110,9 +121,12 @@ struct rt_scene {
             if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess) {
                 wf.reset();
                 for (void* p : allocations) (void)hipFree(p);
-                if (d_acc) (void)hipFree(d_acc);
-                if (ev0) (void)hipEventDestroy(ev0);
-                if (ev1) (void)hipEventDestroy(ev1);
+                for (Slot& sl : slots) {
+                    if (sl.d_acc) (void)hipFree(sl.d_acc);
+                    if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+                    if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+                    if (sl.done) (void)hipEventDestroy(sl.done);
+                }
                 (void)hipSetDevice(prev);
             }
         }
@@ -384,12 +398,21 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         }
         p[1].w = int_bits(rank[sid]);
     }
-    if (s.has_tree && ft.root_is_leaf) s.prims[3 * n_tree].w = uint_bits(1u | kMetaLast);
+    // The dummy slot is read by whatever test the kernel build compiles in (the spheres-only and quads-only builds
+    // ignore the type bits): make it a record that test can never hit — a triangle with zero edges (det = 0), the
+    // extra sphere with a NaN radius (disc > 0 fails), the extra quad with a zero normal (|denom| < 1e-8) below.
+    if (s.has_tree && ft.root_is_leaf) {
+        const uint32_t kind = s.dev.tree_kind;
+        s.prims[3 * n_tree].w = kind == 2u   ? uint_bits(0u | kMetaLast | ((uint32_t)d.n_spheres << kMetaIndexShift))
+                                : kind == 3u ? uint_bits(2u | kMetaLast | ((uint32_t)d.n_quads << kMetaIndexShift))
+                                             : uint_bits(1u | kMetaLast);
+    }
 
-    s.spheres.resize(4 * d.n_spheres);
-    s.sphere_end.assign(3 * std::max<size_t>(d.n_spheres, 1), 0.0);
+    s.spheres.assign(4 * (d.n_spheres + 1), 0.0);  // + the never-hit dummy
+    s.spheres[4 * d.n_spheres + 3] = std::nan("");
+    s.sphere_end.assign(3 * (d.n_spheres + 1), 0.0);
     s.ext = false;
-    s.sphere_mat.resize(d.n_spheres);
+    s.sphere_mat.assign(d.n_spheres + 1, 0);
     for (size_t i = 0; i < d.n_spheres; ++i) {
         for (int a = 0; a < 3; ++a) s.spheres[4 * i + a] = d.spheres[i].center[a];
         s.spheres[4 * i + 3] = d.spheres[i].radius;
@@ -399,8 +422,8 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         s.sphere_mat[i] = d.spheres[i].material;
     }
     // gate of a sphere / quad = box of the reference tree's leaf that holds it (see leaf_gate_hit in device_rt.h)
-    s.sphere_gate.assign(6 * std::max<size_t>(d.n_spheres, 1), 0.0);
-    s.quad_gate.assign(6 * std::max<size_t>(d.n_quads, 1), 0.0);
+    s.sphere_gate.assign(6 * (d.n_spheres + 1), 0.0);
+    s.quad_gate.assign(6 * (d.n_quads + 1), 0.0);
     for (const BvhNode& n : s.bvh.nodes) {
         if (!n.is_leaf()) continue;
         for (int32_t k = n.first; k < n.first + n.count; ++k) {
@@ -416,8 +439,8 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
             if (encloses) gate[0] = -INFINITY;
         }
     }
-    s.quads.assign(16 * d.n_quads, 0.0);
-    s.quad_mat.resize(d.n_quads);
+    s.quads.assign(16 * (d.n_quads + 1), 0.0);  // + the never-hit dummy (all zeros)
+    s.quad_mat.assign(d.n_quads + 1, 0);
     for (size_t i = 0; i < d.n_quads; ++i) {
         const rt_quad& q = d.quads[i];
         V3 u{q.u[0], q.u[1], q.u[2]}, v{q.v[0], q.v[1], q.v[2]}, w{q.w[0], q.w[1], q.w[2]};
@@ -645,12 +668,15 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.nodes64 = upload(*s, s->nodes64);
         s->dev.prims64 = upload(*s, s->prims64);
         std::vector<DevCounters> zero(1);
-        s->d_counters = const_cast<DevCounters*>(upload(*s, zero));
+        for (rt_scene::Slot& sl : s->slots) {
+            sl.d_counters = const_cast<DevCounters*>(upload(*s, zero));
+            HIP_CHECK(hipEventCreate(&sl.ev0));
+            HIP_CHECK(hipEventCreate(&sl.ev1));
+            HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cus = (uint32_t)prop.multiProcessorCount;
-        HIP_CHECK(hipEventCreate(&s->ev0));
-        HIP_CHECK(hipEventCreate(&s->ev1));
         *out = s.release();
         return 0;
     } catch (const std::exception& e) {
@@ -672,6 +698,48 @@ int rt_scene_leaf_order(const rt_scene* scene, int32_t* out_surface_ids) {
     return 0;
 }
 
+// Which kernel organisation a call runs (the other organisations defer to the persistent kernel for textures,
+// moving spheres and media; the pooled one only pays when rays traverse a tree, and packs depth and pixel into
+// one word).
+enum class Organisation { Persistent, Pool, Wavefront };
+static Organisation organisation(const rt_scene& scene, const DevScene& dev, const DevRenderParams& rp, int32_t kernel) {
+    if (kernel == RT_KERNEL_WAVEFRONT) return dev.ext ? Organisation::Persistent : Organisation::Wavefront;
+    if (kernel == RT_KERNEL_POOL)
+        return dev.has_tree && !dev.ext && rp.max_depth <= 63u && pool_kernel_supports(rp.width, rp.height, scene.stack_depth)
+                   ? Organisation::Pool
+                   : Organisation::Persistent;
+    if (kernel == RT_KERNEL_PERSISTENT) return Organisation::Persistent;
+    throw std::runtime_error("unknown kernel selector " + std::to_string(kernel));
+}
+
+static void print_stage_debug(const DevCounters& c) {
+    for (int k = 0; k < 4; ++k)
+        fprintf(stderr, "[stages] %d: trips %llu lanes/trip %.1f cycles/trip %.0f total Gcycles %.2f\n", k, c.stage_trips[k],
+                c.stage_trips[k] ? (double)c.stage_lanes[k] / (double)c.stage_trips[k] : 0.0,
+                c.stage_trips[k] ? (double)c.stage_cycles[k] / (double)c.stage_trips[k] : 0.0,
+                (double)c.stage_cycles[k] * 1e-9);
+    for (int pass = 0; pass < 2; ++pass) {
+        fprintf(stderr, pass ? "[waves finished, per 0.5 ms]" : "[waves out of work, per 0.5 ms]");
+        int last = 63;
+        while (last > 0 && (pass ? c.finish_hist : c.exhaust_hist)[last] == 0) --last;
+        for (int k = 0; k <= last; ++k) fprintf(stderr, " %u", (pass ? c.finish_hist : c.exhaust_hist)[k]);
+        fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "[drain time, per 0.25 ms]");
+    int last = 63;
+    while (last > 0 && c.drain_hist[last] == 0) --last;
+    for (int k = 0; k <= last; ++k) fprintf(stderr, " %u", c.drain_hist[k]);
+    fprintf(stderr, "\n%u waves drained for more than 2 ms\n", c.n_late);
+    for (unsigned k = 0; k < std::min(c.n_late, 32u); ++k)
+        fprintf(stderr, "  out of work %.2f ms, done %.2f ms; node/leaf/shade trips %llu %llu %llu lanes %llu %llu %llu\n",
+                c.late[k][0] * 1e-5, c.late[k][1] * 1e-5, c.late[k][2], c.late[k][3], c.late[k][4], c.late[k][5],
+                c.late[k][6], c.late[k][7]);
+    if (c.stage_trips[2])
+        fprintf(stderr, "[shade trip] bounce+accumulate %.0f, regenerate %.0f, loose+bounds %.0f cycles/trip\n",
+                (double)c.stage_cycles[4] / (double)c.stage_trips[2], (double)c.stage_cycles[5] / (double)c.stage_trips[2],
+                (double)c.stage_cycles[6] / (double)c.stage_trips[2]);
+}
+
 int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream_v,
                      rt_stats* stats) {
     if (!scene || !params || !d_rgb_sum) return set_error("rt_render_device: null argument");
@@ -681,43 +749,44 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
         hipStream_t stream = (hipStream_t)stream_v;
         DevScene dev;
         camera_for_size(*scene, rp.width, rp.height, dev);
+        const Organisation org = organisation(*scene, dev, rp, params->kernel);
+        // this call's scratch: the slots in turn (the wavefront form's queues exist once: always slot 0)
+        rt_scene::Slot& sl = scene->slots[org == Organisation::Wavefront ? 0 : scene->next_slot];
+        if (org != Organisation::Wavefront) scene->next_slot = (scene->next_slot + 1) % rt_scene::kSlots;
+        // the slot's previous use, if it was enqueued on another stream, must have ended before this one starts
+        if (sl.used && sl.last_stream != stream) HIP_CHECK(hipStreamWaitEvent(stream, sl.done, 0));
         const bool count = stats && params->collect_stats;
-        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, sizeof(DevCounters), stream));
-        if (stats) HIP_CHECK(hipEventRecord(scene->ev0, stream));
+        if (count) HIP_CHECK(hipMemsetAsync(sl.d_counters, 0, sizeof(DevCounters), stream));
+        if (stats) HIP_CHECK(hipEventRecord(sl.ev0, stream));
         uint32_t n_launches = 1;
-        // textures and moving spheres exist in the persistent kernel only: the other organisations defer to it
-        if (params->kernel == RT_KERNEL_PERSISTENT || params->kernel == RT_KERNEL_POOL ||
-            (params->kernel == RT_KERNEL_WAVEFRONT && dev.ext)) {
-            // scratch: the tile-planar accumulator, kept with the scene and grown on demand
+        if (org != Organisation::Wavefront) {
+            // the tile-planar accumulator is kept with the slot and grown on demand
             const size_t need = persistent_acc_bytes(rp.width, rp.height);
-            if (scene->acc_bytes < need) {
-                if (scene->d_acc) {
-                    HIP_CHECK(hipStreamSynchronize(stream));
-                    HIP_CHECK(hipFree(scene->d_acc));
-                    scene->d_acc = nullptr, scene->acc_bytes = 0;
+            if (sl.acc_bytes < need) {
+                if (sl.d_acc) {
+                    if (sl.used) HIP_CHECK(hipEventSynchronize(sl.done));  // whatever stream used it last
+                    HIP_CHECK(hipFree(sl.d_acc));
+                    sl.d_acc = nullptr, sl.acc_bytes = 0;
                 }
-                HIP_CHECK(hipMalloc((void**)&scene->d_acc, need));
-                scene->acc_bytes = need;
+                HIP_CHECK(hipMalloc((void**)&sl.d_acc, need));
+                sl.acc_bytes = need;
             }
-            // the pooled kernel only pays when rays traverse a tree; it packs depth and pixel into one word
-            const bool pooled = params->kernel == RT_KERNEL_POOL && dev.has_tree && !dev.ext && rp.max_depth <= 63u &&
-                                pool_kernel_supports(rp.width, rp.height, scene->stack_depth);
-            HIP_CHECK((pooled ? launch_render_pool : launch_render_persistent)(
-                dev, rp, scene->stack_depth, scene->n_cus, scene->d_acc, d_rgb_sum, scene->d_counters,
-                &scene->d_counters->work, count, stream));
-        } else if (params->kernel == RT_KERNEL_WAVEFRONT) {
-            if (!scene->wf) scene->wf = std::make_unique<WavefrontState>();
-            HIP_CHECK(render_wavefront(*scene->wf, dev, rp, scene->stack_depth, d_rgb_sum, scene->d_counters, count,
-                                       stream, &n_launches));
+            HIP_CHECK((org == Organisation::Pool ? launch_render_pool : launch_render_persistent)(
+                dev, rp, scene->stack_depth, scene->n_cus, sl.d_acc, d_rgb_sum, sl.d_counters, &sl.d_counters->work, count,
+                stream));
         } else {
-            throw std::runtime_error("unknown kernel selector " + std::to_string(params->kernel));
+            if (!scene->wf) scene->wf = std::make_unique<WavefrontState>();
+            HIP_CHECK(render_wavefront(*scene->wf, dev, rp, scene->stack_depth, d_rgb_sum, sl.d_counters, count, stream,
+                                       &n_launches));
         }
+        if (stats) HIP_CHECK(hipEventRecord(sl.ev1, stream));
+        HIP_CHECK(hipEventRecord(sl.done, stream));
+        sl.used = true, sl.last_stream = stream;
         if (stats) {
-            HIP_CHECK(hipEventRecord(scene->ev1, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             std::memset(stats, 0, sizeof *stats);
             float ms = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+            HIP_CHECK(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
             stats->kernel_ms = ms;
             stats->n_launches = n_launches;
             const uint64_t mine =
@@ -725,39 +794,10 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
             stats->samples = (uint64_t)rp.width * rp.height * mine;
             if (count) {
                 DevCounters c;
-                HIP_CHECK(hipMemcpy(&c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+                HIP_CHECK(hipMemcpy(&c, sl.d_counters, sizeof c, hipMemcpyDeviceToHost));
                 stats->segments = c.segments, stats->node_visits = c.node_visits, stats->tri_tests = c.tri_tests;
                 stats->sphere_tests = c.sphere_tests, stats->quad_tests = c.quad_tests;
-                if (getenv("RT_STAGE_DEBUG"))
-                    for (int k = 0; k < 4; ++k)
-                        fprintf(stderr, "[stages] %d: trips %llu lanes/trip %.1f cycles/trip %.0f total Gcycles %.2f\n", k,
-                                c.stage_trips[k],
-                                c.stage_trips[k] ? (double)c.stage_lanes[k] / (double)c.stage_trips[k] : 0.0,
-                                c.stage_trips[k] ? (double)c.stage_cycles[k] / (double)c.stage_trips[k] : 0.0,
-                                (double)c.stage_cycles[k] * 1e-9);
-                if (getenv("RT_STAGE_DEBUG")) {
-                    for (int pass = 0; pass < 2; ++pass) {
-                        fprintf(stderr, pass ? "[waves finished, per 0.5 ms]" : "[waves out of work, per 0.5 ms]");
-                        int last = 63;
-                        while (last > 0 && (pass ? c.finish_hist : c.exhaust_hist)[last] == 0) --last;
-                        for (int k = 0; k <= last; ++k) fprintf(stderr, " %u", (pass ? c.finish_hist : c.exhaust_hist)[k]);
-                        fprintf(stderr, "\n");
-                    }
-                    fprintf(stderr, "[drain time, per 0.25 ms]");
-                    int last = 63;
-                    while (last > 0 && c.drain_hist[last] == 0) --last;
-                    for (int k = 0; k <= last; ++k) fprintf(stderr, " %u", c.drain_hist[k]);
-                    fprintf(stderr, "\n%u waves drained for more than 2 ms\n", c.n_late);
-                    for (unsigned k = 0; k < std::min(c.n_late, 32u); ++k)
-                        fprintf(stderr, "  out of work %.2f ms, done %.2f ms; node/leaf/shade trips %llu %llu %llu lanes %llu %llu %llu\n",
-                                c.late[k][0] * 1e-5, c.late[k][1] * 1e-5, c.late[k][2], c.late[k][3], c.late[k][4],
-                                c.late[k][5], c.late[k][6], c.late[k][7]);
-                }
-                if (getenv("RT_STAGE_DEBUG") && c.stage_trips[2])
-                    fprintf(stderr, "[shade trip] bounce+accumulate %.0f, regenerate %.0f, loose+bounds %.0f cycles/trip\n",
-                            (double)c.stage_cycles[4] / (double)c.stage_trips[2],
-                            (double)c.stage_cycles[5] / (double)c.stage_trips[2],
-                            (double)c.stage_cycles[6] / (double)c.stage_trips[2]);
+                if (getenv("RT_STAGE_DEBUG")) print_stage_debug(c);
             }
         }
         return 0;
@@ -794,6 +834,10 @@ int rt_primary_hits(rt_scene* scene, uint32_t width, uint32_t height, int precis
         if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 31))
             throw std::runtime_error("bad image size");
         if (precision != 32 && precision != 64) throw std::runtime_error("precision must be 32 or 64");
+        // the f64 kernel's depth-first walk keeps at most one entry per level plus one on its private stack
+        if (precision == 64 && scene->info.max_depth + 1 > kPrimary64Stack)
+            throw std::runtime_error("reference-topology BVH of depth " + std::to_string(scene->info.max_depth) +
+                                     " exceeds the parity kernel's stack (" + std::to_string(kPrimary64Stack) + " entries)");
         DeviceGuard guard(scene->device);
         const size_t n = (size_t)width * height;
         HIP_CHECK(hipMalloc((void**)&d_id, n * sizeof(int32_t)));

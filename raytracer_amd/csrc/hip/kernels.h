@@ -20,6 +20,7 @@ hipError_t launch_render_pool(const DevScene& sc, const DevRenderParams& rp, uin
                               bool stats, hipStream_t stream);
 hipError_t launch_tonemap(const float* d_rgb_sum, uint32_t n_values, double n_samples, uint8_t* d_out,
                           hipStream_t stream);
+constexpr uint32_t kPrimary64Stack = 128;  // entries of primary64_kernel's private stack; the caller checks the depth
 hipError_t launch_primary64(const DevScene& sc, uint32_t width, uint32_t height, int32_t* d_prim_id, double* d_t,
                             hipStream_t stream);
 hipError_t launch_primary32(const DevScene& sc, uint32_t width, uint32_t height, uint32_t tree_depth,

@@ -109,7 +109,7 @@ __global__ void primary64_kernel(DevScene sc, uint32_t width, uint32_t height, i
     const V inv = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};  // trace.rs:18
     const double t_min = 0.001, t_inf = __builtin_inf();
 
-    int stack[128];
+    int stack[kPrimary64Stack];  // rt_primary_hits rejects trees deeper than kPrimary64Stack - 1
     int sp = 0;
     stack[sp++] = 0;
     double best_t = t_inf;
@@ -120,7 +120,7 @@ __global__ void primary64_kernel(DevScene sc, uint32_t width, uint32_t height, i
         if (node >= 0) {
             const Node64& n = sc.nodes64[node];
             for (int c = 0; c < 2; ++c)
-                if (n.child[c] != kNoChild && aabb_hit(n.lo[c], n.hi[c], origin, inv, t_min, t_inf) && sp < 127)
+                if (n.child[c] != kNoChild && aabb_hit(n.lo[c], n.hi[c], origin, inv, t_min, t_inf))
                     stack[sp++] = n.child[c];
         } else {
             int slot = ~node;

@@ -222,3 +222,47 @@ def test_frame_pipeline_with_rccl_work_objects():
     ) % ROOT
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_two_renders_of_one_scene_in_flight_on_two_streams(ra):
+    """rt_render_device keeps two scratch sets per scene (include/rt.h): two renders enqueued back to back on two
+    streams, neither awaited in between, give the frames serial renders give; so does a third and fourth call
+    that re-use the sets (ordered behind their previous use by an event wait), with a different frame size that
+    makes one set grow."""
+    import torch
+
+    s = ra.Scene(ra.load_scene(scene_path("teapot"), 1.5), 0)
+    w, h, sn = 384, 256, 6
+    want_a, _ = s.render(w, h, sn, seed=1)
+    want_b, _ = s.render(w, h, sn, seed=2)
+    want_c, _ = s.render(w + 64, h, 2, seed=3)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    fa = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    fb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    fc = torch.zeros((h, w + 64, 3), dtype=torch.float32, device="cuda:0")
+    fd = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    s.render_device(fa.data_ptr(), w, h, sn, seed=1, stream=s1.cuda_stream, want_stats=False)
+    s.render_device(fb.data_ptr(), w, h, sn, seed=2, stream=s2.cuda_stream, want_stats=False)
+    s.render_device(fc.data_ptr(), w + 64, h, 2, seed=3, stream=s2.cuda_stream, want_stats=False)  # set 0 again, from s2
+    s.render_device(fd.data_ptr(), w, h, sn, seed=1, stream=s1.cuda_stream, want_stats=False)      # set 1 again, from s1
+    torch.cuda.synchronize()
+    assert np.allclose(fa.cpu().numpy(), want_a, rtol=1e-5, atol=1e-6)
+    assert np.allclose(fb.cpu().numpy(), want_b, rtol=1e-5, atol=1e-6)
+    assert np.allclose(fc.cpu().numpy(), want_c, rtol=1e-5, atol=1e-6)
+    assert np.allclose(fd.cpu().numpy(), want_a, rtol=1e-5, atol=1e-6)
+    s.close()
+
+
+def test_single_leaf_trees_of_one_kind(ra, ref, tmp_path):
+    """--no-bvh on a spheres-only tree: the synthetic root's dummy slot is read by the spheres-only build as a
+    sphere — a NaN-radius one that no ray can hit (api.cpp flatten_render)."""
+    path = synth.many_prims(tmp_path, n_spheres=28, n_quads=0, with_mesh=False)
+    w, h, sn = 96, 64, 3
+    a = ra.Scene(ra.load_scene(path, w / h, True), 0)
+    b = ra.Scene(ra.load_scene(path, w / h, False), 0)
+    assert b.info().render_max_leaf == 31
+    ia, _ = a.render(w, h, sn)
+    ib, _ = b.render(w, h, sn)
+    assert _same_image(ia, ib, sn * sn)
+    a.close(), b.close()
