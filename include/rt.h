@@ -230,6 +230,17 @@ typedef struct rt_stats {
 int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream,
                      rt_stats* stats);
 
+/* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Calls no hipMalloc / hipFree or other
+ * allocating routine: the kernels' scratch (tile accumulator + chunk cursor) is a static device array of the
+ * library, 24 MiB + 4 KiB per GPU, held until the process ends; its address is looked up once per device at
+ * rt_scene_create.  Limits: RT_KERNEL_PERSISTENT only, collect_stats == 0, frames of at most 32 768 8x8 tiles
+ * (ceil(width/8) * ceil(height/8); 1920x1080 is 32 400) - anything larger is rejected with an error, as is a
+ * scene created with RT_DEVICE_NONE.  Enqueues on `stream` and returns; same output as rt_render_device.  Every
+ * call on a GPU shares that GPU's one scratch array: calls that overlap on one GPU (two streams, two scenes, two
+ * threads) race - order them on one stream or with events. */
+int rt_render_device_noalloc(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream);
+
 /* Same, into HOST memory (synchronous; allocates and frees a device framebuffer). */
 int rt_render(rt_scene* scene, const rt_render_params* params, float* rgb_sum, rt_stats* stats);
 

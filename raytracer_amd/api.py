@@ -25,7 +25,7 @@ RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_UV_CHECKER, RT_TEX_MARBLE, RT_TEX_IMAGE = 0
 # every symbol include/rt.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "rt_load_scene", "rt_example_scene", "rt_scene_desc_free", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
-    "rt_scene_leaf_order", "rt_render_device", "rt_render", "rt_primary_hits", "rt_tonemap_rgb8",
+    "rt_scene_leaf_order", "rt_render_device", "rt_render_device_noalloc", "rt_render", "rt_primary_hits", "rt_tonemap_rgb8",
     "rt_tonemap_rgb8_device", "rt_write_png", "rt_set_verbose", "rt_last_error", "rt_version",
 ]
 
@@ -172,6 +172,8 @@ def lib() -> C.CDLL:
     L.rt_scene_leaf_order.restype = i32
     L.rt_render_device.argtypes = [vp, C.POINTER(RtRenderParams), vp, vp, C.POINTER(RtStats)]
     L.rt_render_device.restype = i32
+    L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(RtRenderParams), vp, vp]
+    L.rt_render_device_noalloc.restype = i32
     L.rt_render.argtypes = [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]
     L.rt_render.restype = i32
     L.rt_primary_hits.argtypes = [vp, u32, u32, i32, vp, vp]
@@ -373,6 +375,13 @@ class Scene:
         _check(lib().rt_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream),
                                       C.byref(st) if want_stats else None))
         return _stats(st) if want_stats else None
+
+    def render_device_noalloc(self, d_ptr: int, width, height, sn, *, max_depth=40, seed=1, stratum_begin=0,
+                              stratum_step=1, stream: int = 0, sampler=RT_SAMPLER_DIRECT, kernel=RT_KERNEL_PERSISTENT):
+        """render_device through the entry point that allocates nothing (static device scratch; persistent kernel,
+        frames up to 32 768 tiles); enqueues on ``stream`` and returns."""
+        p = self._params(width, height, sn, max_depth, seed, stratum_begin, stratum_step, kernel, False, sampler)
+        _check(lib().rt_render_device_noalloc(self._h, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream)))
 
     def primary_hits(self, width, height, precision=64):
         ids = np.empty((height, width), dtype=np.int32)

@@ -96,6 +96,9 @@ struct rt_scene {
     static constexpr int kSlots = 2;
     Slot slots[kSlots];
     int next_slot = 0;
+    // rt_render_device_noalloc: this device's copy of the library's static scratch (looked up at scene creation)
+    float* static_acc = nullptr;
+    DevCounters* static_counters = nullptr;
     std::unique_ptr<WavefrontState> wf;  // its queues are one set: wavefront renders all use slot 0
 
     // flattened host copies (kept for host-only inspection and tests)
@@ -677,6 +680,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cus = (uint32_t)prop.multiProcessorCount;
+        // set-up of rt_render_device_noalloc: the static scratch's address on this device (this device is current)
+        HIP_CHECK(persistent_static_scratch(device, &s->static_acc, &s->static_counters));
         *out = s.release();
         return 0;
     } catch (const std::exception& e) {
@@ -803,6 +808,33 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
         return 0;
     } catch (const std::exception& e) {
         return set_error(std::string("rt_render_device: ") + e.what());
+    }
+}
+
+int rt_render_device_noalloc(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream_v) {
+    if (!scene || !params || !d_rgb_sum) return set_error("rt_render_device_noalloc: null argument");
+    try {
+        DevRenderParams rp = make_params(*scene, *params);
+        if (params->kernel != RT_KERNEL_PERSISTENT)
+            throw std::runtime_error("only RT_KERNEL_PERSISTENT renders without allocating");
+        if (params->collect_stats) throw std::runtime_error("collect_stats needs rt_render_device");
+        const uint64_t tiles = (uint64_t)((rp.width + 7u) >> 3) * ((rp.height + 7u) >> 3);
+        if (tiles > kNoAllocMaxTiles)
+            throw std::runtime_error("frame of " + std::to_string(rp.width) + "x" + std::to_string(rp.height) + " = " +
+                                     std::to_string(tiles) + " 8x8 tiles exceeds the static scratch (" +
+                                     std::to_string(kNoAllocMaxTiles) + " tiles, e.g. 1920x1080): use rt_render_device");
+        if (!scene->static_acc) throw std::runtime_error("the static scratch was not set up for this scene's device");
+        DeviceGuard guard(scene->device);
+        DevScene dev;
+        camera_for_size(*scene, rp.width, rp.height, dev);
+        // launch_render_persistent clears the accumulator it needs and the chunk cursor on `stream` before the
+        // kernel: the scratch keeps the previous call's contents, nothing else of it is read
+        HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, scene->static_acc, d_rgb_sum,
+                                           scene->static_counters, &scene->static_counters->work, false,
+                                           (hipStream_t)stream_v));
+        return 0;
+    } catch (const std::exception& e) {
+        return set_error(std::string("rt_render_device_noalloc: ") + e.what());
     }
 }
 

@@ -11,6 +11,11 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
                                     uint32_t* work_counter, bool stats, hipStream_t stream);
 // bytes of the tile-planar accumulator the persistent kernel adds into (d_acc above)
 size_t persistent_acc_bytes(uint32_t width, uint32_t height);
+// rt_render_device_noalloc: the largest frame (in 8x8 tiles; 1920x1080 is 32 400) whose accumulator fits the
+// library's static device scratch, and that scratch's addresses on `device`, which must be the current device
+// on the first call for it (render_persistent.hip)
+constexpr uint32_t kNoAllocMaxTiles = 32768;
+hipError_t persistent_static_scratch(int device, float** d_acc, DevCounters** d_counters);
 // tile-planar accumulator -> row-major interleaved framebuffer
 hipError_t launch_resolve(const float* d_acc, uint32_t width, uint32_t height, float* d_rgb_sum, hipStream_t stream);
 // pooled persistent kernel (render_pool.hip): same arguments; false = use launch_render_persistent instead

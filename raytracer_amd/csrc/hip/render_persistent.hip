@@ -13,6 +13,7 @@
 // 24 B per pixel, and the only HBM traffic besides scene fetches.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "device_rt.h"
 #include "kernels.h"
@@ -406,6 +407,38 @@ hipError_t launch_resolve(const float* d_acc, uint32_t width, uint32_t height, f
 
 size_t persistent_acc_bytes(uint32_t width, uint32_t height) {
     return (size_t)((width + 7u) >> 3) * ((height + 7u) >> 3) * 192u * sizeof(float);
+}
+
+// ---- scratch of rt_render_device_noalloc (include/rt.h): the tile-planar accumulator of a frame of up to
+// kNoAllocMaxTiles 8x8 tiles, then one DevCounters block (the chunk cursor).  One copy per GPU, held from module
+// load until the process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress: kernels,
+// memsets and copies take the device address that call returns, looked up once per device below.
+constexpr size_t kStaticAccBytes = (size_t)kNoAllocMaxTiles * 192u * sizeof(float);
+constexpr size_t kStaticScratchBytes = kStaticAccBytes + 4096u;
+static_assert(sizeof(DevCounters) <= 4096u, "the counters block must fit the scratch's tail");
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[kMaxDevices] = {};
+
+hipError_t persistent_static_scratch(int device, float** d_acc, DevCounters** d_counters) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) return e;
+        if (current != device) return hipErrorInvalidDevice;  // each GPU has its own copy at its own address
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = ptr;
+    }
+    *d_acc = (float*)g_scratch_ptr[device];
+    *d_counters = (DevCounters*)((unsigned char*)g_scratch_ptr[device] + kStaticAccBytes);
+    return hipSuccess;
 }
 
 // main.rs:177-180, 209-221 (average in f64 like the reference's Vec3 / f64)
