@@ -48,6 +48,7 @@ def lib():
         L.ref_scatter.argtypes = [C.c_int, dp, C.c_double, dp, dp, C.c_int, C.c_uint64, dp]
         L.ref_reflectance.restype = C.c_double
         L.ref_reflectance.argtypes = [C.c_double, C.c_double]
+        L.ref_sphere_uv.argtypes = [dp, dp]
         L.ref_rng_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, dp]
         _lib = L
     return _lib
@@ -193,6 +194,13 @@ def sample(which, sampler, state, n):
     out = np.zeros((n, 3))
     lib().ref_sample(which, sampler, state, n, _p(out))
     return out
+
+
+def sphere_uv(n):
+    """get_sphere_uv (surfaces.rs:108-118) of a unit outward normal."""
+    v, out = _d(n), np.zeros(2)
+    lib().ref_sphere_uv(_p(v), _p(out))
+    return float(out[0]), float(out[1])
 
 
 def rng_stream(seed, pixel, stratum, n):

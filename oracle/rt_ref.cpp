@@ -359,12 +359,15 @@ struct Surface {
     Vec3 center(double t) const { return (1. - t) * center_start + t * center_end; }  // surfaces.rs:52-54
 
     // get_sphere_uv, surfaces.rs:108-118 (the reference computes it at every sphere hit; only the uv textures read it)
-    void sphere_uv(Vec3 n, Hit& h) const {
-        if (material->tex != UVChecker && material->tex != Image) return;
+    static void get_sphere_uv(Vec3 n, double& u, double& v) {
         const double PI = 3.14159265358979323846;
         const double theta = std::acos(-n.y);
         const double phi = std::atan2(-n.z, n.x) + PI;
-        h.u = phi / (2.0 * PI), h.v = theta / PI;
+        u = phi / (2.0 * PI), v = theta / PI;
+    }
+    void sphere_uv(Vec3 n, Hit& h) const {
+        if (material->tex != UVChecker && material->tex != Image) return;
+        get_sphere_uv(n, h.u, h.v);
     }
 
     Aabb bounding_box() const {
@@ -1031,6 +1034,8 @@ void ref_sample(int which, int sampler, uint64_t state, int n, double* out3n) {
     }
 }
 double ref_reflectance(double cosine, double ri) { return reflectance(cosine, ri); }
+// get_sphere_uv (surfaces.rs:108-118) of a unit outward normal: out = u, v
+void ref_sphere_uv(const double* n3, double* out2) { Surface::get_sphere_uv({n3[0], n3[1], n3[2]}, out2[0], out2[1]); }
 // first n uniforms of the stream for (seed, pixel, stratum)
 void ref_rng_stream(uint64_t seed, uint32_t pixel, uint32_t stratum, int n, double* out) {
     Rng r = rng_init(seed, pixel, stratum);
