@@ -1,6 +1,6 @@
-"""Procedural example scenes (scene/example.rs:69-79): `one-weekend` — the reference CLI's default scene — and
-`cornell`.  The reference draws one-weekend from thread_rng(), so there is no fixture to compare the scene's
-content with; what is pinned is the generator's structure (counts, fixed spheres, camera) and, on the GPU,
+"""The eight procedural example scenes (scene/example.rs:53-79; `one-weekend` is the reference CLI's default).
+The reference draws the random ones from thread_rng(), so there is no fixture to compare their content with; what
+is pinned is the generator's structure (counts, fixed spheres, textures, motion, media, camera) and, on the GPU,
 render parity with the oracle over the very arrays the generator produced."""
 import subprocess
 
@@ -120,7 +120,7 @@ def test_examples_camera_matches_oracle_and_unsupported_names_are_refused(ra, re
                                          ("two-perlin", 120, 80, 4), ("earth", 90, 60, 3),
                                          ("cornell-smoke", 96, 96, 5), ("final-scene", 100, 100, 4)])
 def test_example_renders_match_the_oracle(ra, ref, name, w, h, sn):
-    from test_gpu_parity import F32_ID_MISMATCH, T_REL, _check_image
+    from test_gpu_parity import T_REL, _check_image, classify_f32
 
     d = ra.example_scene(name, w / h, seed=11)
     scene = ra.Scene(d, 0)
@@ -129,12 +129,12 @@ def test_example_renders_match_the_oracle(ra, ref, name, w, h, sn):
     ids, t = scene.primary_hits(w, h, precision=64)
     assert np.array_equal(ids, rid) and np.array_equal(t, rt)
     ids32, t32 = scene.primary_hits(w, h, precision=32)
-    mism = ids32 != rid
-    assert mism.mean() <= F32_ID_MISMATCH
-    same = ~mism & (rid >= 0)
-    rel = np.abs(t32[same] - rt[same]) / rt[same]
+    swaps, flips, n_rel, max_rel = classify_f32(ids32, t32, rid, rt)
+    # the cornell examples' camera sits on the box's plane of symmetry: pixel-centre rays of the middle column
+    # run along the boxes' edges (16 flips and 6 swaps of 9216 pixels measured), as in quads.yaml
+    assert flips <= max(4, 3e-3 * rid.size) and swaps <= max(8, 5e-3 * rid.size), (name, swaps, flips)
     # f32 ray directions: a grazing hit on a radius-1000 ground sphere (the horizon row) amplifies their rounding
-    assert np.mean(rel > T_REL) <= 1e-3 and np.max(rel, initial=0.0) <= 10 * T_REL
+    assert n_rel <= 1e-3 * rid.size and max_rel <= 10 * T_REL, (name, n_rel, max_rel)
     for sampler in (0, 1):
         want, _ = oracle.render(w, h, sn, threads=16, sampler=sampler)
         for kernel in (0, 1, 2):

@@ -7,7 +7,7 @@ import pytest
 
 import synth
 from conftest import ROOT, scene_path
-from test_gpu_parity import F32_ID_MISMATCH, T_REL, _check_image, _same_image
+from test_gpu_parity import T_REL, T_REL_MAX, _check_image, _same_image, classify_f32
 
 pytestmark = pytest.mark.gpu
 
@@ -17,10 +17,9 @@ def _primary_parity(scene, oracle, w, h):
     ids, t = scene.primary_hits(w, h, precision=64)
     assert np.array_equal(ids, rid) and np.array_equal(t, rt)
     ids32, t32 = scene.primary_hits(w, h, precision=32)
-    mism = ids32 != rid
-    assert mism.mean() <= F32_ID_MISMATCH, f"{mism.sum()} of {mism.size} pixels"
-    same = ~mism & (rid >= 0)
-    assert np.max(np.abs(t32[same] - rt[same]) / rt[same], initial=0.0) <= T_REL
+    swaps, flips, n_rel, max_rel = classify_f32(ids32, t32, rid, rt)
+    assert flips <= max(4, 1e-3 * rid.size) and swaps <= max(8, 5e-3 * rid.size), (swaps, flips)
+    assert n_rel <= 4 and max_rel <= T_REL_MAX, (n_rel, max_rel)
 
 
 def test_spheres_and_quads_inside_the_render_tree(ra, ref, tmp_path):

@@ -3,11 +3,18 @@ golden vectors.  Needs an MI355X:  pytest -m gpu.
 
 Bars (BASELINE.json north_star):
   * primary-hit primitive ids EXACT and t within 1e-5 relative — met bit-for-bit by the f64 AOV kernel
-    (precision=64).  The f32 kernel (precision=32, the arithmetic the render kernels use) is held to a stated
-    mismatch budget: ids may differ on at most F32_ID_MISMATCH of the pixels (silhouette / shared-edge pixels
-    where f32 rounding picks the neighbouring primitive), t within 1e-5 relative wherever ids agree.
+    (precision=64), which is therefore also a full-resolution oracle on the device.  The f32 kernel (precision=32:
+    the arithmetic and pruned traversal the render kernels use) is compared with it at the golden size and at
+    BASELINE's full frame sizes, and its mismatches are split into
+      tie-swaps  ids differ, both hit, |dt|/t <= 1e-5: two surfaces meet at the pixel-centre ray (a shared mesh
+                 edge, a box corner) and f32 picks the neighbour; harmless, reported, loosely bounded;
+      flips      hit <-> miss, or |dt|/t > 1e-5: budgeted per scene at 2x the measured count (floor 4 pixels);
+    t must be within 1e-5 relative wherever ids agree, except on a budgeted handful of grazing pixels (a ray
+    direction rounded to f32 moves a silhouette-grazing root by more), and within 2e-4 everywhere.
+    Measured table: DESIGN.md §2 (tools/parity_table.py).
   * images at equal spp: per-channel RMSE <= IMG_RMSE and mean luminance within IMG_LUM relative.  Oracle and
-    GPU draw identical variates, so most paths coincide and the residual is the f32-vs-f64 path divergence.
+    GPU draw identical variates, so most paths coincide and the residual is the f32-vs-f64 path divergence:
+    measured RMSE <= 0.0015 at 16 spp and <= 0.0007 at 1024 spp, luminance within 2.7e-4 (cornell_lucy, the worst).
 """
 import os
 
@@ -19,11 +26,30 @@ from conftest import ROOT, scene_path
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell", "cornell_lucy", "teapot", "lucy", "dual", "distant", "light", "quads"]
-F32_ID_MISMATCH = 5e-3   # fraction of pixels (worst case: cornell 64x64, whose pixel-centre rays run exactly
-                         # along the box's corner edges: 9 of 4096 pixels pick the adjoining wall or none)
 T_REL = 1e-5
-IMG_RMSE = 0.02          # on linear radiance averaged over spp (values are O(0.1..1))
-IMG_LUM = 0.01           # relative
+T_REL_MAX = 2e-4         # grazing pixels
+IMG_RMSE = 0.003         # on linear radiance averaged over spp (values are O(0.1..1)); 2x the measured worst
+IMG_LUM = 6e-4           # relative; 2x the measured worst
+# f32 AOV vs f64 AOV, (frame, tie-swap bound, flip budget, pixels with rel dt > 1e-5 among equal ids): measured
+# swaps/flips/pixels in the comment.  quads.yaml: the quads' edges lie in the plane x = 0, which the pixel
+# centres of column W/2 - 1 look along exactly ((pi + 1) / W = 1/2, Q5): on-edge in f64, either side in f32.
+F32_BUDGET = {
+    "golden": {"cornell": (40, 4, 4), "cornell_lucy": (40, 4, 4), "teapot": (8, 4, 4), "lucy": (8, 4, 4),      # 12/0/0 12/0/0 0/0/0 0/0/0
+               "dual": (8, 4, 4), "distant": (8, 4, 4), "light": (8, 4, 4), "quads": (8, 40, 4)},               # 0/0/0 0/0/0 0/0/0 0/20/0
+    "full": {("lucy", 1920, 1080): (40, 4, 4), ("teapot", 1920, 1080): (40, 4, 16),                            # 9/1/1 13/2/8
+             ("dual", 1920, 1080): (40, 16, 26), ("cornell_lucy", 3840, 2160): (1000, 96, 4)},                  # 16/8/13 400/48/1
+}
+
+
+def classify_f32(ids32, t32, ids64, t64):
+    """(tie-swaps, flips, id-equal pixels with rel dt > T_REL, max rel dt among id-equal pixels)."""
+    both = (ids64 >= 0) & (ids32 >= 0)
+    rel = np.zeros_like(t64)
+    rel[both] = np.abs(t32[both] - t64[both]) / t64[both]
+    same = ids64 == ids32
+    swap = ~same & both & (rel <= T_REL)
+    flip = ~same & ~swap
+    return int(swap.sum()), int(flip.sum()), int((rel[same & both] > T_REL).sum()), float(rel[same & both].max(initial=0.0))
 
 
 def golden(name):
@@ -71,10 +97,22 @@ def test_primary_hits_f32_within_budget(scenes, name):
     g = golden(name)
     h, w = g["prim_id"].shape
     ids, t = scenes(name, w / h).primary_hits(w, h, precision=32)
-    mism = ids != g["prim_id"]
-    assert mism.mean() <= F32_ID_MISMATCH, f"{mism.sum()} of {mism.size} pixels"
-    same = ~mism & (g["prim_id"] >= 0)
-    assert np.max(np.abs(t[same] - g["t"][same]) / g["t"][same], initial=0.0) <= T_REL
+    swaps, flips, n_rel, max_rel = classify_f32(ids, t, g["prim_id"], g["t"])
+    b_swaps, b_flips, b_rel = F32_BUDGET["golden"][name]
+    assert swaps <= b_swaps and flips <= b_flips and n_rel <= b_rel and max_rel <= T_REL_MAX, (swaps, flips, n_rel, max_rel)
+
+
+@pytest.mark.parametrize("name,w,h", list(F32_BUDGET["full"]))
+def test_primary_hits_f32_vs_f64_at_full_size(scenes, name, w, h):
+    """BASELINE's frame sizes: the render arithmetic's closest hits against the bit-exact f64 kernel's."""
+    s = scenes(name, w / h)
+    ids64, t64 = s.primary_hits(w, h, precision=64)
+    ids32, t32 = s.primary_hits(w, h, precision=32)
+    swaps, flips, n_rel, max_rel = classify_f32(ids32, t32, ids64, t64)
+    b_swaps, b_flips, b_rel = F32_BUDGET["full"][(name, w, h)]
+    assert flips <= b_flips, f"{flips} flips of {ids64.size} pixels (budget {b_flips})"
+    assert flips / ids64.size <= 1e-4  # BASELINE north_star's "exact" up to silhouette pixels; SURVEY appendix A
+    assert swaps <= b_swaps and n_rel <= b_rel and max_rel <= T_REL_MAX, (swaps, flips, n_rel, max_rel)
 
 
 def test_no_bvh_gives_identical_primary_hits(scenes):
@@ -87,12 +125,13 @@ def test_no_bvh_gives_identical_primary_hits(scenes):
 
 
 # ------------------------------------------------------------------ images
-def _check_image(got_sum, want_sum, n, name):
+def _check_image(got_sum, want_sum, n, name, rmse_bar=IMG_RMSE, lum_bar=IMG_LUM):
     got, want = got_sum.astype(np.float64) / n, want_sum / n
     assert np.isfinite(got).all()
     rmse = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))
-    assert np.all(rmse <= IMG_RMSE), (name, rmse)
-    assert abs(got.mean() - want.mean()) <= IMG_LUM * max(want.mean(), 1e-6), (name, got.mean(), want.mean())
+    assert np.all(rmse <= rmse_bar), (name, rmse)
+    lum = abs(got.mean() - want.mean()) / max(want.mean(), 1e-6)
+    assert lum <= lum_bar, (name, lum, got.mean(), want.mean())
 
 
 @pytest.mark.parametrize("sampler", [0, 1])
@@ -113,14 +152,20 @@ def test_image_matches_golden(ra, scenes, name, kernel, sampler):
     assert 0 < st.segments <= 1.02 * int(g["segments"])
 
 
-@pytest.mark.parametrize("name,w,h,sn", [("teapot", 160, 90, 6), ("cornell_lucy", 96, 96, 6), ("distant", 160, 90, 8)])
+@pytest.mark.parametrize("name,w,h,sn", [("teapot", 160, 90, 6), ("cornell_lucy", 96, 96, 6), ("distant", 160, 90, 8),
+                                         ("teapot", 96, 54, 32), ("cornell_lucy", 96, 96, 32), ("lucy", 96, 54, 32),
+                                         ("dual", 96, 54, 32)])
 def test_image_matches_oracle_higher_spp(scenes, ref, name, w, h, sn):
+    """Up to 1024 spp per mesh scene, all three organisations, both samplers."""
     o = ref.RefScene.from_yaml(scene_path(name), w / h)
     for sampler in (0, 1):
         want, _ = o.render(w, h, sn, threads=16, sampler=sampler)
         for kernel in (0, 1, 2):
             img, _ = scenes(name, w / h).render(w, h, sn, kernel=kernel, sampler=sampler)
-            _check_image(img, want, sn * sn, name)
+            # cornell at 36 spp: one path in ~2000 parts ways in f32 and a path that finds the 15-unit light moves
+            # its pixel by 0.2: measured RMSE 0.0062 and luminance 7e-4 (0.0007 and 2.7e-4 at 1024 spp)
+            low = (name, sn) == ("cornell_lucy", 6)
+            _check_image(img, want, sn * sn, name, rmse_bar=0.012 if low else IMG_RMSE, lum_bar=2e-3 if low else IMG_LUM)
 
 
 def _same_image(a, b, n):
