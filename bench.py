@@ -41,35 +41,51 @@ def reduce_framebuffer(fb, world: int) -> None:
 
 
 class FramePipeline:
-    """Two framebuffers in turn: frame i's sum-reduce runs (on RCCL's own stream) beside frame i+1's render, and
-    frame i is finished — reduce awaited, `finish(buffer)` called, e.g. the tonemap — after frame i+1's render
-    was issued.  A buffer is rendered into again only after the frame it held was finished, in stream order.
-    With one rank there is nothing to overlap: a frame is finished in its own step."""
+    """Two framebuffers in turn, each with a stream of its own when `streams` is given: frame i+1's render is
+    enqueued on the other stream while frame i's render drains (rt_render_device keeps two scratch sets per scene
+    for exactly this), frame i's sum-reduce runs on RCCL's stream beside frame i+1's render, and frame i is finished
+    — reduce awaited on its stream, `finish(buffer, k)` called, e.g. the tonemap — after frame i+1's render was
+    issued.  A buffer is rendered into again only after the frame it held was finished, in its stream's order.
+    `render(buffer, k)` and `finish(buffer, k)` get the buffer's index (= its stream's).  With one rank there is
+    nothing to overlap: a frame is finished in its own step."""
 
-    def __init__(self, buffers, world: int, render, finish):
-        self.buffers, self.world, self.render, self.finish = buffers, world, render, finish
+    def __init__(self, buffers, world: int, render, finish, streams=None):
+        self.buffers, self.world, self.render, self.finish, self.streams = buffers, world, render, finish, streams
         self.work = [None] * len(buffers)
         self.open = [False] * len(buffers)
         self.i = 0
 
+    def _on(self, k: int):
+        if self.streams is None:
+            import contextlib
+
+            return contextlib.nullcontext()
+        import torch
+
+        return torch.cuda.stream(self.streams[k])
+
     def _finish(self, k: int) -> None:
-        if self.work[k] is not None:
-            self.work[k].wait()  # the current stream waits for the reduce; the host does not
-            self.work[k] = None
-        if self.open[k]:
-            self.finish(self.buffers[k])
-            self.open[k] = False
+        with self._on(k):
+            if self.work[k] is not None:
+                self.work[k].wait()  # buffer k's stream waits for the reduce; the host does not
+                self.work[k] = None
+            if self.open[k]:
+                self.finish(self.buffers[k], k)
+                self.open[k] = False
 
     def step(self):
         k = self.i % len(self.buffers)
         self.i += 1
         self._finish(k)  # no-op unless the pipeline is deeper than its buffers
-        out = self.render(self.buffers[k])
-        self.open[k] = True
-        if self.world > 1:
-            import torch.distributed as dist
+        with self._on(k):
+            out = self.render(self.buffers[k], k)
+            self.open[k] = True
+            if self.world > 1:
+                import torch.distributed as dist
 
-            self.work[k] = dist.reduce(self.buffers[k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+                # RCCL's stream first waits for what buffer k's stream holds so far: this frame's render
+                self.work[k] = dist.reduce(self.buffers[k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        if self.world > 1:
             self._finish((k - 1) % len(self.buffers))  # the frame before: its reduce ran beside this render
         else:
             self._finish(k)
@@ -109,33 +125,87 @@ def cache_bytes_per_sample(st) -> float:
     return (st.node_visits * 64 + st.tri_tests * 84 + st.sphere_tests * 16 + st.quad_tests * 72) / n
 
 
+PMC_PROFILE = os.path.join("profiles", "r2_final_pmc.json")
+
+
+def kernel_sources_sha() -> str:
+    """Hash of the device sources the dominant kernel is built from; profiles/*_pmc.json records the one it was
+    taken on (tools/pmc_to_json.py), so a profile of older kernels is not passed off as this run's."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer_amd", "csrc", "hip")
+    for name in ("device_scene.h", "device_rt.h", "render_persistent.hip"):
+        with open(os.path.join(d, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload: str):
-    """Memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE + WRITE_SIZE, KB -> bytes), when they were taken on this very workload; else None.  The
-    counters cannot be read from inside the timed process, so this is the profile of the same command."""
-    path = os.path.join(ROOT, "profiles", "r1_final_pmc.json")
+    """(bytes, source): memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (FETCH_SIZE + WRITE_SIZE, KB -> bytes; MI355X_MICROARCH.md, HBM section) — only when they were taken on
+    this very workload AND on these very kernel sources; else (None, reason).  The counters cannot be read from
+    inside the timed process: this is the profile of the same command, labelled as such."""
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, PMC_PROFILE)) as fh:
             p = json.load(fh)
     except OSError:
-        return None
+        return None, f"{PMC_PROFILE} missing"
     if p.get("workload") != workload:
-        return None
-    return round((p["FETCH_SIZE_KB"] + p["WRITE_SIZE_KB"]) * 1024.0)
+        return None, f"{PMC_PROFILE} is of another workload"
+    if p.get("kernel_sources_sha") != kernel_sources_sha():
+        return None, f"{PMC_PROFILE} was taken on other kernel sources ({p.get('kernel_sources_sha')})"
+    return round((p["FETCH_SIZE_KB"] + p["WRITE_SIZE_KB"]) * 1024.0), f"{PMC_PROFILE} (rocprofv3 --pmc, same command, commit {p.get('commit', '?')})"
 
 
-def cpu_baseline(scene_file: str, width: int, height: int, sn: int, threads: int):
+def host_cpus():
+    """(threads to use, CPUs this process may run on, CPUs of the machine, model name).  The reference's rayon pool
+    uses every CPU it may run on (main.rs:122-127); so does the baseline — bounded by the scheduler affinity, the
+    cgroup CPU quota and, on the GPU box, the per-GPU CPU share the harness exports as OMP_NUM_THREADS."""
+    allowed = len(os.sched_getaffinity(0))
+    use, why = allowed, "sched_getaffinity"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max" and int(quota) // int(period) >= 1 and int(quota) // int(period) < use:
+            use, why = int(quota) // int(period), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    if omp.isdigit() and 0 < int(omp) < use:
+        use, why = int(omp), "OMP_NUM_THREADS (the harness's CPU share per GPU)"
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return use, allowed, os.cpu_count() or allowed, model, why
+
+
+def cpu_baseline(scene_file: str, width: int, height: int, seconds: float, sampler: int):
     """The oracle (the f64 CPU restatement of the reference's render loop, Q1 re-trace cost included) timed on
-    this box's host cores on a bounded sample of the same workload: same scene and resolution, sn*sn spp."""
+    this box's host CPUs on a bounded sample of the same workload: same scene, resolution and sampler, at the
+    spp that a short calibration run says takes about `seconds` (>= 30 s of CPU work)."""
     from oracle import ref
 
+    threads, allowed, total, model, why = host_cpus()
     o = ref.RefScene.from_yaml(scene_file, width / height)
     t0 = time.perf_counter()
-    o.render(width, height, sn, max_depth=40, seed=1, threads=threads)
+    o.render(width, height, 2, max_depth=40, seed=1, threads=threads, sampler=sampler)
+    per_spp = (time.perf_counter() - t0) / 4.0
+    sn = max(2, min(64, int(round((seconds / per_spp) ** 0.5))))
+    t0 = time.perf_counter()
+    o.render(width, height, sn, max_depth=40, seed=1, threads=threads, sampler=sampler)
     dt = time.perf_counter() - t0
     n = width * height * sn * sn
-    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{os.path.basename(scene_file)} {width}x{height} at {sn * sn} spp ({n} samples, {dt:.1f} s)"}
+    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "cores_allowed": allowed,
+            "cores_total": total, "cores_bound_by": why, "cpu_model": model, "kind": "port",
+            "sample": f"{os.path.basename(scene_file)} {width}x{height} at {sn * sn} spp ({n} samples, {dt:.1f} s of "
+                      f"{threads} threads), {'direct' if sampler else 'reference'} sampler"}
 
 
 def main() -> None:
@@ -152,7 +222,7 @@ def main() -> None:
                     help="unit-sphere/disk sampling: loop-free direct maps (default) or the reference's rejection loops; "
                          "same distributions (tests/test_golden.py, tests/test_gpu_parity.py)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sn", type=int, default=10, help="strata per axis of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU work of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--png", default=None, help="rank 0 writes the last frame here")
     args = ap.parse_args()
@@ -192,22 +262,38 @@ def main() -> None:
     fb = fbs[0]
     rgb8 = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
     begin, step_ = strata_slice(rank, world)
+    # one rank: everything on torch's current stream, the library times its kernels with HIP events on it.
+    # several ranks: a stream per framebuffer, so that the next frame's render fills the CUs this frame's draining
+    # waves leave idle; the library is then not asked for statistics (that would synchronise the stream) and the
+    # launches are timed with events recorded on their own streams.
+    streams = [torch.cuda.Stream(dev) for _ in fbs] if world > 1 else None
     stream = torch.cuda.current_stream(dev).cuda_stream
-    kernel_ms = []
+    kernel_ms, kernel_events = [], []
+    my_strata = len(range(begin, sn * sn, step_))
 
-    def render(buf):
-        st = scene.render_device(buf.data_ptr(), w, h, sn, max_depth=40, seed=args.seed, stratum_begin=begin,
-                                 stratum_step=step_, kernel=kernel, stream=stream, sampler=sampler)
-        kernel_ms.append(st.kernel_ms)  # HIP events on `stream`, around this step's render kernels
-        return st
+    def render(buf, k):
+        if streams is None:
+            st = scene.render_device(buf.data_ptr(), w, h, sn, max_depth=40, seed=args.seed, stratum_begin=begin,
+                                     stratum_step=step_, kernel=kernel, stream=stream, sampler=sampler)
+            kernel_ms.append(st.kernel_ms)  # HIP events on `stream`, around this step's render kernels
+            return st
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(streams[k])
+        scene.render_device(buf.data_ptr(), w, h, sn, max_depth=40, seed=args.seed, stratum_begin=begin,
+                            stratum_step=step_, kernel=kernel, stream=streams[k].cuda_stream, sampler=sampler,
+                            want_stats=False)
+        e1.record(streams[k])
+        kernel_events.append((e0, e1))
+        return None
 
-    def tonemap(buf):
+    def tonemap(buf, k):
         if rank == 0:
-            ra.api._check(ra.lib().rt_tonemap_rgb8_device(buf.data_ptr(), w, h, sn * sn, rgb8.data_ptr(), stream))
+            on = stream if streams is None else streams[k].cuda_stream
+            ra.api._check(ra.lib().rt_tonemap_rgb8_device(buf.data_ptr(), w, h, sn * sn, rgb8.data_ptr(), on))
 
     # a step = render this rank's strata slice of one frame + the frame's sum-reduce + tonemap on rank 0; with
-    # several ranks the reduce of one frame overlaps the render of the next (FramePipeline)
-    frames = FramePipeline(fbs, world, render, tonemap)
+    # several ranks the reduce of one frame and the drain of its render overlap the render of the next
+    frames = FramePipeline(fbs, world, render, tonemap, streams)
     one_step = frames.step
 
     def fence():
@@ -220,13 +306,17 @@ def main() -> None:
     for _ in range(args.warmup):
         one_step()
     fence()
-    kernel_ms.clear()
+    kernel_ms.clear(), kernel_events.clear()
     t0 = time.perf_counter()
-    last = None
     for _ in range(args.steps):
-        last = one_step()
+        one_step()
     fence()
     elapsed = time.perf_counter() - t0
+    # overlapped launches share the GPU: their event-bracketed times overlap too, so with several ranks the
+    # average launch duration is taken as the step time (render-bound: the reduce and tonemap hide beside it)
+    if kernel_events:
+        kernel_ms = [elapsed / args.steps * 1e3] * args.steps
+        kernel_events.clear()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -235,12 +325,31 @@ def main() -> None:
     samples_per_step = w * h * sn * sn
     value = samples_per_step * args.steps / elapsed / 1e6
 
+    # The same steps with the other sampler (outside `value`'s timed region): the headline runs the direct maps,
+    # the reference's own rejection loops are reported beside it.
+    other = ra.RT_SAMPLER_REFERENCE if sampler == ra.RT_SAMPLER_DIRECT else ra.RT_SAMPLER_DIRECT
+    main_sampler, sampler = sampler, other
+    one_step()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed_other = time.perf_counter() - t1
+    if world > 1:
+        tmax = torch.tensor([elapsed_other], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed_other = float(tmax.item())
+    sampler = main_sampler
+    kernel_ms = kernel_ms[:args.steps]
+    kernel_events.clear()
+
     # Algorithmic work per sample from the counting build of the same kernel, outside the timed region,
     # at reduced spp (per-sample counts do not depend on spp).
     cnt = scene.render_device(fb.data_ptr(), w, h, min(sn, 4), max_depth=40, seed=args.seed, kernel=kernel,
                               collect_stats=True, stream=stream, sampler=sampler)
     fl = flops_per_sample(cnt)
-    my_samples = last.samples  # samples this rank rendered per step
+    my_samples = w * h * my_strata  # samples this rank rendered per step
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved_tflops = fl * my_samples / avg_kernel_s / 1e12
     # HBM-side traffic the algorithm needs per launch (persistent kernels): clear of the tile-planar accumulator
@@ -257,19 +366,24 @@ def main() -> None:
     if rank == 0:
         workload = (f"scenes/{args.scene}.yaml {w}x{h} {sn * sn} spp, max_depth 40, "
                     f"{args.kernel} kernel, {args.sampler} sampler")
+        traffic, traffic_source = pmc_traffic(workload) if world == 1 else (None, "single-GPU profile only")
         line = {
             "metric": "Msamples/sec (whole node)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": f"the reference's own scene file scenes/{args.scene}.yaml + its OBJ mesh (not synthetic)",
             "config": {"workload": workload, "seconds_per_frame": round(elapsed / args.steps, 4),
                        "parallelism": f"strata-sharded x{world}, 1 RCCL sum-reduce/frame" if world > 1 else "1 GPU",
                        "scene_surfaces": int(info.n_surfaces), "render_bvh_nodes": int(info.render_nodes),
                        "render_bvh_depth": int(info.render_depth), "loose_prims": int(info.n_loose),
-                       "scene_setup_s": round(setup_s, 3)},
+                       "scene_setup_s": round(setup_s, 3),
+                       "other_sampler": {"sampler": "reference" if main_sampler == ra.RT_SAMPLER_DIRECT else "direct",
+                                         "value": round(samples_per_step * args.steps / elapsed_other / 1e6, 3),
+                                         "unit": "Msamples/s", "ms_per_step": round(elapsed_other / args.steps * 1e3, 3)}},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved_tflops, 4), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),
-                         "traffic": pmc_traffic(workload) if world == 1 else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": {ra.RT_KERNEL_PERSISTENT: "render_persistent_kernel", ra.RT_KERNEL_POOL: "render_pool_kernel",
                                     ra.RT_KERNEL_WAVEFRONT: "wf_extend+wf_shade"}[kernel],
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 3), "flops_per_sample": round(fl, 1),
@@ -282,8 +396,7 @@ def main() -> None:
                                  "unit": "GB/s", "frac": round(hbm_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS, 6)}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(scene_file, w, h, args.cpu_sn, threads)
+            line["cpu_baseline"] = cpu_baseline(scene_file, w, h, args.cpu_seconds, 1 if main_sampler == ra.RT_SAMPLER_DIRECT else 0)
         if args.png:
             ra.write_png(args.png, rgb8.cpu().numpy())
         print(json.dumps(line), flush=True)

@@ -69,12 +69,12 @@ def _pipeline_worker(rank, world, port, out_path):
     frame = [0]
     finished = []
 
-    def render(buf):
+    def render(buf, k):
         frame[0] += 1
         buf.fill_(float((rank + 1) * frame[0]))  # rank r's "slice" of frame f
         return frame[0]
 
-    def finish(buf):
+    def finish(buf, k):
         finished.append(buf.clone())
 
     pipe = bench.FramePipeline([torch.zeros(4, 3), torch.zeros(4, 3)], world, render, finish)
@@ -103,7 +103,7 @@ def test_frame_pipeline_single_rank_finishes_in_step():
     import bench
 
     log = []
-    pipe = bench.FramePipeline([torch.zeros(2)], 1, lambda b: log.append("render") or len(log), lambda b: log.append("finish"))
+    pipe = bench.FramePipeline([torch.zeros(2)], 1, lambda b, k: log.append("render") or len(log), lambda b, k: log.append("finish"))
     pipe.step(), pipe.step()
     pipe.drain()
     assert log == ["render", "finish", "render", "finish"]

@@ -191,9 +191,10 @@ def test_library_before_torch_shares_one_hip_runtime():
 
 
 def test_frame_pipeline_with_rccl_work_objects():
-    """bench.py's FramePipeline on the GPU with real RCCL work objects (a one-rank group: the box has one GPU):
-    renders into two torch framebuffers in turn, async reduce, stream-ordered wait, finish — every finished
-    frame equals a plain render of the same strata slice."""
+    """bench.py's FramePipeline on the GPU as several ranks run it — a stream per framebuffer, renders enqueued
+    without host synchronisation (the next frame's render beside this frame's drain), real RCCL work objects (a
+    one-rank group: the box has one GPU), stream-ordered wait, finish: every finished frame equals a plain render
+    of the same strata slice."""
     import subprocess
     import sys
 
@@ -205,16 +206,19 @@ def test_frame_pipeline_with_rccl_work_objects():
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
         "s = ra.Scene(ra.load_scene('scenes/teapot.yaml', 1.5), 0)\n"
-        "want, _ = s.render(96, 64, 4, stratum_begin=1, stratum_step=2)\n"
-        "stream = torch.cuda.current_stream().cuda_stream\n"
-        "fbs = [torch.zeros((64, 96, 3), dtype=torch.float32, device='cuda:0') for _ in range(2)]\n"
+        "want, _ = s.render(192, 128, 8, stratum_begin=1, stratum_step=2)\n"
+        "streams = [torch.cuda.Stream() for _ in range(2)]\n"
+        "fbs = [torch.zeros((128, 192, 3), dtype=torch.float32, device='cuda:0') for _ in range(2)]\n"
         "done = []\n"
-        "def render(buf):\n"
-        "    return s.render_device(buf.data_ptr(), 96, 64, 4, stratum_begin=1, stratum_step=2, stream=stream)\n"
-        "pipe = bench.FramePipeline(fbs, 2, render, lambda buf: done.append(buf.clone()))\n"
-        "for _ in range(5): pipe.step()\n"
+        "def render(buf, k):\n"
+        "    s.render_device(buf.data_ptr(), 192, 128, 8, stratum_begin=1, stratum_step=2, stream=streams[k].cuda_stream, want_stats=False)\n"
+        "def finish(buf, k):\n"
+        "    assert torch.cuda.current_stream() == streams[k]\n"
+        "    done.append(buf.clone())\n"
+        "pipe = bench.FramePipeline(fbs, 2, render, finish, streams)\n"
+        "for _ in range(7): pipe.step()\n"
         "pipe.drain(); torch.cuda.synchronize()\n"
-        "assert len(done) == 5\n"
+        "assert len(done) == 7\n"
         "for d in done: assert np.allclose(d.cpu().numpy(), want, rtol=1e-5, atol=1e-6)\n"
         "dist.destroy_process_group()\n"
         "print('ok')\n"
