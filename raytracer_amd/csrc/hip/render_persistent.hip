@@ -42,6 +42,11 @@ struct PersistentPlan {
     // teapot.yaml (1/8 of the 1024 strata, as an 8-GPU run gives each rank).
     uint32_t phase_first[kPhases + 1], phase_end[kPhases], phase_strata[kPhases];
     uint32_t n_chunks;       // n_tiles * phase_end[kPhases - 1]
+    // Dynamic LDS of a block, in this order: the loose records (n_loose x kLooseRecQuads uint4), the traversal stack
+    // [stack_levels][kBlock] ints, the waves' tile sums (3 x 64 floats each).  Sized per launch — tree depth and
+    // loose count are the scene's — because the kernel lives on its occupancy: 160 KB of LDS per CU hold five
+    // blocks only up to 32 KB each.
+    uint32_t stack_levels;
 };
 
 // Lane stages, encoded in `node`: an inner node id (>= 0) = one node_step pending; a leaf reference (< 0,
@@ -65,17 +70,18 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int STACK, bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE>
+template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE>
 __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
-    __shared__ int lds_stack[STACK * kBlock];
-    __shared__ uint4 lds_loose[kMaxLoose * kLooseRecQuads];
+    extern __shared__ uint4 lds_dyn[];
+    uint4* lds_loose = lds_dyn;
+    int* lds_stack = (int*)(lds_dyn + sc.n_loose * kLooseRecQuads);
+    float* lds_acc = (float*)(lds_stack + plan.stack_levels * kBlock);
     int* stack = lds_stack + threadIdx.x;
     for (uint32_t i = threadIdx.x; i < sc.n_loose * kLooseRecQuads; i += kBlock) lds_loose[i] = sc.loose_rec[i];
     // radiance sums of the tile this wave's current chunk belongs to (3 x 64 floats per wave)
-    __shared__ float lds_acc[(kBlock / 64) * 192];
     float* wacc = lds_acc + (threadIdx.x >> 6) * 192;
     wacc[threadIdx.x & 63u] = 0.f, wacc[64 + (threadIdx.x & 63u)] = 0.f, wacc[128 + (threadIdx.x & 63u)] = 0.f;
     uint32_t acc_tile = 0xffffffffu;  // wave-uniform
@@ -311,43 +317,37 @@ __global__ void resolve_kernel(const float* __restrict__ acc, uint32_t width, ui
     rgb_sum[3 * i + 2] = a[128];
 }
 
-template <int STACK, bool STATS, bool DIRECT>
-static void launch_one(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
-                       float* d_acc, DevCounters* counters, uint32_t* work_counter, hipStream_t stream) {
-    // scenes with textures or moving spheres run the EXT build, those with constant media the EXT + MEDIA one; the
-    // others keep the lean one (each feature costs registers in every stage, used or not)
-    if (sc.ext && sc.n_media)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, true, 0>), dim3(blocks), dim3(kBlock), 0, stream,
-                           sc, rp, plan, d_acc, counters, work_counter);
-    else if (sc.ext && sc.tree_kind == 2u)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false, 2>), dim3(blocks), dim3(kBlock), 0, stream,
-                           sc, rp, plan, d_acc, counters, work_counter);
-    else if (sc.ext)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, true, false, 0>), dim3(blocks), dim3(kBlock), 0, stream,
-                           sc, rp, plan, d_acc, counters, work_counter);
-    else if (sc.tree_kind == 1u)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 1>), dim3(blocks), dim3(kBlock), 0,
-                           stream, sc, rp, plan, d_acc, counters, work_counter);
-    else if (sc.tree_kind == 2u)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 2>), dim3(blocks), dim3(kBlock), 0,
-                           stream, sc, rp, plan, d_acc, counters, work_counter);
-    else if (sc.tree_kind == 3u)
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 3>), dim3(blocks), dim3(kBlock), 0,
-                           stream, sc, rp, plan, d_acc, counters, work_counter);
-    else
-        hipLaunchKernelGGL((render_persistent_kernel<STACK, STATS, DIRECT, false, false, 0>), dim3(blocks), dim3(kBlock), 0,
-                           stream, sc, rp, plan, d_acc, counters, work_counter);
+size_t persistent_lds_bytes(const DevScene& sc, const PersistentPlan& plan) {
+    return (size_t)sc.n_loose * kLooseRecQuads * sizeof(uint4) + (size_t)plan.stack_levels * kBlock * sizeof(int) +
+           (size_t)(kBlock / 64) * 192 * sizeof(float);
 }
 
-template <int STACK>
-static hipError_t launch_stack(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
-                               float* d_rgb_sum, DevCounters* counters, uint32_t* work_counter, bool stats,
-                               hipStream_t stream) {
+template <bool STATS, bool DIRECT>
+static void launch_one(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
+                       float* d_acc, DevCounters* counters, uint32_t* work_counter, hipStream_t stream) {
+    const size_t lds = persistent_lds_bytes(sc, plan);
+    // scenes with textures or moving spheres run the EXT build, those with constant media the EXT + MEDIA one; the
+    // others keep the lean one (each feature costs registers in every stage, used or not)
+#define RT_LAUNCH(EXT_, MEDIA_, TREE_)                                                                                  \
+    hipLaunchKernelGGL((render_persistent_kernel<STATS, DIRECT, EXT_, MEDIA_, TREE_>), dim3(blocks), dim3(kBlock), lds, \
+                       stream, sc, rp, plan, d_acc, counters, work_counter)
+    if (sc.ext && sc.n_media) RT_LAUNCH(true, true, 0);
+    else if (sc.ext && sc.tree_kind == 2u) RT_LAUNCH(true, false, 2);
+    else if (sc.ext) RT_LAUNCH(true, false, 0);
+    else if (sc.tree_kind == 1u) RT_LAUNCH(false, false, 1);
+    else if (sc.tree_kind == 2u) RT_LAUNCH(false, false, 2);
+    else if (sc.tree_kind == 3u) RT_LAUNCH(false, false, 3);
+    else RT_LAUNCH(false, false, 0);
+#undef RT_LAUNCH
+}
+
+static hipError_t launch_any(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
+                             float* d_acc, DevCounters* counters, uint32_t* work_counter, bool stats, hipStream_t stream) {
     const bool direct = rp.sampler != 0;
-    if (stats && direct) launch_one<STACK, true, true>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
-    if (stats && !direct) launch_one<STACK, true, false>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
-    if (!stats && direct) launch_one<STACK, false, true>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
-    if (!stats && !direct) launch_one<STACK, false, false>(sc, rp, plan, blocks, d_rgb_sum, counters, work_counter, stream);
+    if (stats && direct) launch_one<true, true>(sc, rp, plan, blocks, d_acc, counters, work_counter, stream);
+    if (stats && !direct) launch_one<true, false>(sc, rp, plan, blocks, d_acc, counters, work_counter, stream);
+    if (!stats && direct) launch_one<false, true>(sc, rp, plan, blocks, d_acc, counters, work_counter, stream);
+    if (!stats && !direct) launch_one<false, false>(sc, rp, plan, blocks, d_acc, counters, work_counter, stream);
     return hipGetLastError();
 }
 
@@ -389,12 +389,10 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // harmless (they start when a slot frees up and find the counter exhausted).
     const uint32_t blocks = std::min<uint32_t>(n_cus * 8u, (plan.n_chunks + 3u) / 4u);
     // near-first traversal keeps at most (depth - 1) deferred children
-    // (LDS per block: 24 levels -> 5 blocks per CU, 32 -> 4, 40 -> 3, 56 -> 2)
-    if (tree_depth <= 24) e = launch_stack<24>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
-    else if (tree_depth <= 32) e = launch_stack<32>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
-    else if (tree_depth <= 40) e = launch_stack<40>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
-    else if (tree_depth <= 56) e = launch_stack<56>(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
-    else return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
+    // (LDS per block at ~1 KB per level: up to 27 levels -> 5 blocks per CU, 35 -> 4, 48 -> 3, 56 -> 2)
+    if (tree_depth > 56) return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
+    plan.stack_levels = std::max(tree_depth, 2u) - 1u;
+    e = launch_any(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     if (e != hipSuccess) return e;
     return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);
 }
