@@ -45,9 +45,12 @@ struct PersistentPlan {
     // Dynamic LDS of a block, in this order: the loose records (n_loose x kLooseRecQuads uint4), the traversal stack
     // [stack_levels][kBlock] ints, the waves' tile sums (3 x 64 floats each).  Sized per launch — tree depth and
     // loose count are the scene's — because the kernel lives on its occupancy: 160 KB of LDS per CU hold five
-    // blocks only up to 32 KB each.
+    // blocks only up to 32 KB each.  Last, the waves' batches of pre-drawn camera samples: [gen_words][64] dwords
+    // each — direction (3), generator state (2), and where the scene needs them lens sample (2) and shutter time (1).
     uint32_t stack_levels;
+    uint32_t gen_words;
 };
+constexpr uint32_t kGenLens = 5, kGenTime = 7;  // first word of the lens sample / of the shutter time in a batch
 
 // Lane stages, encoded in `node`: an inner node id (>= 0) = one node_step pending; a leaf reference (< 0,
 // ~slot) = one prim_step pending; kStageShade = the trace is complete (or no path yet): shade / regenerate /
@@ -83,6 +86,7 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
     for (uint32_t i = threadIdx.x; i < sc.n_loose * kLooseRecQuads; i += kBlock) lds_loose[i] = sc.loose_rec[i];
     // radiance sums of the tile this wave's current chunk belongs to (3 x 64 floats per wave)
     float* wacc = lds_acc + (threadIdx.x >> 6) * 192;
+    float* wgen = lds_acc + (kBlock / 64) * 192 + (threadIdx.x >> 6) * plan.gen_words * 64u;
     wacc[threadIdx.x & 63u] = 0.f, wacc[64 + (threadIdx.x & 63u)] = 0.f, wacc[128 + (threadIdx.x & 63u)] = 0.f;
     uint32_t acc_tile = 0xffffffffu;  // wave-uniform
     __syncthreads();
@@ -92,6 +96,12 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
     // wave-uniform cursor over the current chunk
     uint32_t chunk_tile = 0, chunk_first = 0, next_j = 0, chunk_total = 0;  // chunk_first: its first stratum
     bool exhausted = false;
+    // The chunk's samples are drawn 64 at a time — one stratum of the tile's 64 pixels, lane l drawing pixel l's,
+    // all lanes busy, control flow uniform — into the wave's LDS batch; a lane whose path ended picks its sample up
+    // from there.  (Drawn on demand by the lanes that need one, the stream seeding and the camera sample ran on a
+    // third of the lanes of every shade trip.)  gen_j: first sample index of the batch the LDS holds.
+    uint32_t gen_j = 0xffffffffu;
+    const bool has_lens = sc.cam.lens_radius != 0.f;
 
     // per-lane path + traversal state
     F3 thr = {1.f, 1.f, 1.f};
@@ -218,22 +228,41 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
                     chunk_first = plan.phase_first[p] + (group - (p ? plan.phase_end[p - 1] : 0u)) * plan.phase_strata[p];
                     chunk_total = 64u * min(plan.phase_strata[p], plan.phase_first[p + 1] - chunk_first);
                     next_j = 0;
+                    gen_j = 0xffffffffu;
                 }
-                const uint32_t avail = chunk_total - next_j;
+                if (gen_j != (next_j & ~63u)) {  // wave-uniform: draw the batch next_j starts
+                    gen_j = next_j & ~63u;
+                    const uint32_t px = (chunk_tile % plan.tiles_x) * 8u + (lane & 7u);
+                    const uint32_t py = (chunk_tile / plan.tiles_x) * 8u + (lane >> 3);  // image row, 0 = top
+                    const uint32_t stratum = rp.stratum_begin + (chunk_first + (gen_j >> 6)) * rp.stratum_step;
+                    Rng g;
+                    // the stream key is the reference's idx: pi = idx % W, pj = H - idx/W - 1
+                    rng_init(g, seed, py * rp.width + px, stratum);
+                    const CameraSample cs = camera_sample<DIRECT>(sc, rp, px, rp.height - py - 1u, stratum, g);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    // a pixel of the tile that lies outside the frame: NaN marks "no sample"
+                    wgen[lane] = (px < rp.width && py < rp.height) ? cs.d.x : __builtin_nanf("");
+                    wgen[64 + lane] = cs.d.y, wgen[128 + lane] = cs.d.z;
+                    wgen[192 + lane] = __uint_as_float((uint32_t)g.s), wgen[256 + lane] = __uint_as_float((uint32_t)(g.s >> 32));
+                    if (has_lens) wgen[kGenLens * 64u + lane] = cs.rx, wgen[(kGenLens + 1u) * 64u + lane] = cs.ry;
+                    if (EXT) wgen[kGenTime * 64u + lane] = cs.time;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                const uint32_t avail = gen_j + 64u - next_j;  // what is left of the batch (chunks are whole batches)
                 const uint32_t before =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 if (mine && !alive && before < avail) {
-                    const uint32_t j = next_j + before;
-                    const uint32_t in_tile = j & 63u;
-                    const uint32_t px = (chunk_tile % plan.tiles_x) * 8u + (in_tile & 7u);
-                    const uint32_t py = (chunk_tile / plan.tiles_x) * 8u + (in_tile >> 3);  // image row, 0 = top
-                    if (px < rp.width && py < rp.height) {
-                        const uint32_t stratum =
-                            rp.stratum_begin + (chunk_first + (j >> 6)) * rp.stratum_step;
+                    const uint32_t in_tile = (next_j + before) & 63u;
+                    CameraSample cs;
+                    cs.d.x = wgen[in_tile];
+                    if (cs.d.x == cs.d.x) {
+                        cs.d.y = wgen[64 + in_tile], cs.d.z = wgen[128 + in_tile];
+                        rng.s = ((uint64_t)__float_as_uint(wgen[256 + in_tile]) << 32) | __float_as_uint(wgen[192 + in_tile]);
+                        cs.rx = cs.ry = cs.time = 0.f;
+                        if (has_lens) cs.rx = wgen[kGenLens * 64u + in_tile], cs.ry = wgen[(kGenLens + 1u) * 64u + in_tile];
+                        if (EXT) cs.time = wgen[kGenTime * 64u + in_tile];
                         pix = chunk_tile * 64u + in_tile;  // slot in the tile-planar accumulator
-                        // the stream key is the reference's idx: pi = idx % W, pj = H - idx/W - 1
-                        rng_init(rng, seed, py * rp.width + px, stratum);
-                        ray = camera_ray<DIRECT>(sc, rp, px, rp.height - py - 1u, stratum, rng);
+                        ray = camera_ray_of(sc, cs);
                         thr = {1.f, 1.f, 1.f};
                         depth = 0;
                         alive = true;
@@ -319,7 +348,7 @@ __global__ void resolve_kernel(const float* __restrict__ acc, uint32_t width, ui
 
 size_t persistent_lds_bytes(const DevScene& sc, const PersistentPlan& plan) {
     return (size_t)sc.n_loose * kLooseRecQuads * sizeof(uint4) + (size_t)plan.stack_levels * kBlock * sizeof(int) +
-           (size_t)(kBlock / 64) * 192 * sizeof(float);
+           (size_t)(kBlock / 64) * (192 + plan.gen_words * 64) * sizeof(float);
 }
 
 template <bool STATS, bool DIRECT>
@@ -392,6 +421,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // (LDS per block at ~1 KB per level: up to 27 levels -> 5 blocks per CU, 35 -> 4, 48 -> 3, 56 -> 2)
     if (tree_depth > 56) return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
     plan.stack_levels = std::max(tree_depth, 2u) - 1u;
+    plan.gen_words = sc.ext ? kGenTime + 1u : (sc.cam.lens_radius != 0.f ? kGenLens + 2u : kGenLens);
     e = launch_any(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     if (e != hipSuccess) return e;
     return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);
