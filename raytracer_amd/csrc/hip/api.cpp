@@ -75,7 +75,7 @@ struct rt_scene {
     Bvh bvh;         // reference topology (bvh.rs:131-234): parity kernel + tie ranks
     Bvh render_bvh;  // binned-SAH tree the f32 render kernels traverse
     bool has_tree = false;
-    float tree_lo[3] = {0, 0, 0}, tree_hi[3] = {0, 0, 0};
+    float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};  // 16-bit plane grid of the render tree's nodes
     rt_scene_info info{};
     uint32_t stack_depth = 0;  // depth of the flattened render tree incl. a synthetic root
     uint32_t n_cus = 256;
@@ -102,7 +102,8 @@ struct rt_scene {
     std::unique_ptr<WavefrontState> wf;  // its queues are one set: wavefront renders all use slot 0
 
     // flattened host copies (kept for host-only inspection and tests)
-    std::vector<float4> nodes, prims, tri_shade, materials;
+    std::vector<uint4> nodes;
+    std::vector<float4> prims, tri_shade, materials;
     std::vector<int4> loose;
     std::vector<uint4> loose_rec;
     std::vector<int32_t> render_ids;  // surfaces that live in the render tree
@@ -334,35 +335,38 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     }
     const double inflate = maxabs * 0x1p-22;
 
-    s.nodes.assign(4 * std::max<size_t>(ft.n_dev_nodes, 1), float4{0, 0, 0, 0});
+    // The node boxes live on a 16-bit grid over the tree's (inflated) bounds: plane q of axis a = grid_lo[a] +
+    // q * grid_step[a].  lo planes round down and hi planes up, each by one further step, which covers the f32
+    // rounding of the kernels' q * (step / d) + (grid_lo - o) / d many times over (a step is 2^-16 of the extent).
+    double glo[3], gstep[3];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = s.has_tree ? rb.nodes[0].box.lo.get(a) - inflate : 0.0;
+        const double hi = s.has_tree ? rb.nodes[0].box.hi.get(a) + inflate : 1.0;
+        // two steps of margin at either end, so that the outward steps below stay on the grid
+        const double step = std::fmax((hi - lo) / 65531.0, std::fmax(std::fabs(lo), std::fabs(hi)) * 0x1p-20 + 1e-30);
+        gstep[a] = (double)(float)step;
+        if (gstep[a] < step) gstep[a] = (double)std::nextafterf((float)step, INFINITY);
+        glo[a] = (double)round_down(lo - 2.0 * gstep[a]);
+        s.grid_lo[a] = (float)glo[a], s.grid_step[a] = (float)gstep[a];
+        if (glo[a] + 65535.0 * gstep[a] < hi + gstep[a]) throw std::runtime_error("render tree does not fit its plane grid");
+    }
+    s.nodes.assign(2 * std::max<size_t>(ft.n_dev_nodes, 1), uint4{0, 0, 0, 0});
     auto put_child = [&](size_t node, int c, const Aabb& b, int32_t ref) {
-        float lo[3], hi[3];
+        uint32_t w[3];
         for (int a = 0; a < 3; ++a) {
-            lo[a] = round_down(b.lo.get(a) - inflate);
-            hi[a] = round_up(b.hi.get(a) + inflate);
+            const double qlo = std::floor((b.lo.get(a) - inflate - glo[a]) / gstep[a]) - 1.0;
+            const double qhi = std::ceil((b.hi.get(a) + inflate - glo[a]) / gstep[a]) + 1.0;
+            const uint32_t lo = (uint32_t)std::fmin(std::fmax(qlo, 0.0), 65535.0), hi = (uint32_t)std::fmin(std::fmax(qhi, 0.0), 65535.0);
+            w[a] = lo | (hi << 16);
         }
-        float4* n = &s.nodes[4 * node];
-        if (c == 0) {
-            n[0] = {lo[0], lo[1], lo[2], hi[0]};
-            n[1].x = hi[1], n[1].y = hi[2];
-            n[3].x = int_bits(ref);
-        } else {
-            n[1].z = lo[0], n[1].w = lo[1];
-            n[2] = {lo[2], hi[0], hi[1], hi[2]};
-            n[3].y = int_bits(ref);
-        }
+        s.nodes[2 * node + c] = uint4{w[0], w[1], w[2], (uint32_t)ref};
     };
     s.stack_depth = 2;
-    for (int a = 0; a < 3; ++a) {
-        s.tree_lo[a] = s.has_tree ? round_down(rb.nodes[0].box.lo.get(a) - inflate) : 1e30f;
-        s.tree_hi[a] = s.has_tree ? round_up(rb.nodes[0].box.hi.get(a) + inflate) : 1e30f;
-    }
     if (s.has_tree && ft.root_is_leaf) {
-        // synthetic root: child 0 = the leaf; child 1 = a far-away point box over one dummy slot (a
-        // degenerate triangle) that can never be hit
+        // synthetic root: child 0 = the leaf; child 1 = the grid's far corner over one dummy slot that can never
+        // be hit
         put_child(0, 0, rb.nodes[0].box, ~0);
-        Aabb far{{1e30, 1e30, 1e30}, {1e30, 1e30, 1e30}};
-        put_child(0, 1, far, ~(int32_t)n_tree);
+        s.nodes[1] = uint4{0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)~(int32_t)n_tree};
     } else if (s.has_tree) {
         for (size_t i = 0; i < rb.nodes.size(); ++i) {
             const BvhNode& n = rb.nodes[i];
@@ -634,7 +638,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.n_slots = (uint32_t)s->slot_surface.size();
         s->dev.n_loose = (uint32_t)s->loose.size();
         s->dev.has_tree = s->has_tree ? 1u : 0u;
-        for (int a = 0; a < 3; ++a) s->dev.tree_lo[a] = s->tree_lo[a], s->dev.tree_hi[a] = s->tree_hi[a];
+        for (int a = 0; a < 3; ++a) s->dev.grid_lo[a] = s->grid_lo[a], s->dev.grid_step[a] = s->grid_step[a];
         if (device == RT_DEVICE_NONE) {
             s->device = -1;
             *out = s.release();

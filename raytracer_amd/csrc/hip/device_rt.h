@@ -155,25 +155,41 @@ struct TraceStats {
     uint32_t nodes = 0, tris = 0, spheres = 0, quads = 0;
 };
 
-// Camera ray for (pixel, stratum): main.rs:157-174 + camera.rs:76-87.
+// Camera ray for (pixel, stratum): main.rs:157-174 + camera.rs:76-87, in two halves so that the persistent kernel
+// can draw a whole batch of them at once: the draws (direction for a zero lens offset, lens sample scaled by the
+// lens radius, shutter time), and the ray they make.
+struct CameraSample {
+    F3 d;          // ll + u*hor + v*ver - origin (before the lens offset is added back)
+    float rx, ry;  // lens_radius * unit-disk sample
+    float time;
+};
 template <bool DIRECT>
-__device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
-                                          uint32_t stratum, Rng& rng) {
+__device__ __forceinline__ CameraSample camera_sample(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
+                                                      uint32_t stratum, Rng& rng) {
     const uint32_t si = rp.sn_magic ? __umulhi(stratum, rp.sn_magic) : stratum / rp.sn, sj = stratum - si * rp.sn;
     float ju = -0.5f + rp.recip_sn * ((float)si + rng_u01(rng));
     float jv = -0.5f + rp.recip_sn * ((float)sj + rng_u01(rng));
     float s = (float)(pi + 1) + ju;  // in pixel units; *hor_px == (centeru + jitteru*pixel_du)*horizontal
     float t = (float)(pj + 1) + jv;
-    float rx, ry;
-    rng_in_unit_disk<DIRECT>(rng, rx, ry);  // always drawn, even for a pinhole (camera.rs:77)
-    rx *= sc.cam.lens_radius, ry *= sc.cam.lens_radius;
-    const float time = rng_u01(rng);  // shutter time (camera.rs:80): without effect on stationary scenes
-    F3 off = rx * f3(sc.cam.u) + ry * f3(sc.cam.v);
+    CameraSample cs;
+    rng_in_unit_disk<DIRECT>(rng, cs.rx, cs.ry);  // always drawn, even for a pinhole (camera.rs:77)
+    cs.rx *= sc.cam.lens_radius, cs.ry *= sc.cam.lens_radius;
+    cs.time = rng_u01(rng);  // shutter time (camera.rs:80): without effect on stationary scenes
+    cs.d = f3(sc.cam.ll_rel) + s * f3(sc.cam.hor_px) + t * f3(sc.cam.ver_px);
+    return cs;
+}
+__device__ __forceinline__ Ray camera_ray_of(const DevScene& sc, const CameraSample& cs) {
+    const F3 off = cs.rx * f3(sc.cam.u) + cs.ry * f3(sc.cam.v);
     Ray ray;
     ray.o = d3(sc.cam.origin) - d3(off);
-    ray.d = f3(sc.cam.ll_rel) + s * f3(sc.cam.hor_px) + t * f3(sc.cam.ver_px) + off;
-    ray.time = time;
+    ray.d = cs.d + off;
+    ray.time = cs.time;
     return ray;
+}
+template <bool DIRECT>
+__device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
+                                          uint32_t stratum, Rng& rng) {
+    return camera_ray_of(sc, camera_sample<DIRECT>(sc, rp, pi, pj, stratum, rng));
 }
 
 // ---------------------------------------------------------------- primitive tests
@@ -330,28 +346,30 @@ __device__ __forceinline__ void loose_hits(Recs recs, uint32_t n_loose, const Ra
     }
 }
 
-struct SlabRay {  // f32 ray in the form the fma slab test wants: 1/d and o/d per axis
-    float idx, idy, idz, oodx, oody, oodz;
+struct SlabRay {  // f32 ray in the form the fma slab test wants, in grid units: the ray reaches plane q of axis a
+                  // at t = q * a_[a] + b_[a], with a_ = grid_step / d and b_ = (grid_lo - o) / d
+    float ax, ay, az, bx, by, bz;
 };
-__device__ __forceinline__ SlabRay slab_ray(const Ray& ray) {
+__device__ __forceinline__ SlabRay slab_ray(const DevScene& sc, const Ray& ray) {
     SlabRay r;
     const F3 o = tof(ray.o), d = ray.d;
-    // A zero direction component would make lo*inf - o*inf a NaN or a wrongly signed infinity in the fma slab
+    // A zero direction component would make q*inf + (-o)*inf a NaN or a wrongly signed infinity in the fma slab
     // form; clamp |d| away from zero (2^-80) so every slab bound stays finite and correctly ordered.
     const float ooeps = 0x1p-80f;
-    r.idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
-    r.idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
-    r.idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
-    r.oodx = o.x * r.idx, r.oody = o.y * r.idy, r.oodz = o.z * r.idz;
+    const float idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+    const float idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+    const float idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+    r.ax = sc.grid_step[0] * idx, r.ay = sc.grid_step[1] * idy, r.az = sc.grid_step[2] * idz;
+    r.bx = (sc.grid_lo[0] - o.x) * idx, r.by = (sc.grid_lo[1] - o.y) * idy, r.bz = (sc.grid_lo[2] - o.z) * idz;
     return r;
 }
 
-// Does the ray reach the render tree's bounds at all within [tmin, best_t]?  Most sky/ground rays do not, and
-// then skip the traversal stages entirely.
+// Does the ray reach the render tree's bounds (grid planes 0 and 65535) at all within [tmin, best_t]?  Most
+// sky/ground rays do not, and then skip the traversal stages entirely.
 __device__ __forceinline__ bool hits_tree_bounds(const DevScene& sc, const SlabRay& r, float tmin, float best_t) {
-    const float ax = fmaf(sc.tree_lo[0], r.idx, -r.oodx), bx = fmaf(sc.tree_hi[0], r.idx, -r.oodx);
-    const float ay = fmaf(sc.tree_lo[1], r.idy, -r.oody), by = fmaf(sc.tree_hi[1], r.idy, -r.oody);
-    const float az = fmaf(sc.tree_lo[2], r.idz, -r.oodz), bz = fmaf(sc.tree_hi[2], r.idz, -r.oodz);
+    const float ax = r.bx, bx = fmaf(65535.0f, r.ax, r.bx);
+    const float ay = r.by, by = fmaf(65535.0f, r.ay, r.by);
+    const float az = r.bz, bz = fmaf(65535.0f, r.az, r.bz);
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t * 1.0000004f));
     return tn <= tf;
@@ -365,28 +383,25 @@ __device__ __forceinline__ int stack_pop(int* stack, int stride, int& sp) {
 
 // One inner node: test both children's boxes against [tmin, best_t], go to the nearer hit child, defer the
 // other.  Returns the next node (>= 0 inner, < 0 leaf ~first_slot, kTraversalDone).
+__device__ __forceinline__ void child_slab(const uint4 c, const SlabRay& r, float tmin, float tmax_pad, float& tn, float& tf) {
+    const float ax = fmaf((float)(c.x & 0xffffu), r.ax, r.bx), bx = fmaf((float)(c.x >> 16), r.ax, r.bx);
+    const float ay = fmaf((float)(c.y & 0xffffu), r.ay, r.by), by = fmaf((float)(c.y >> 16), r.ay, r.by);
+    const float az = fmaf((float)(c.z & 0xffffu), r.az, r.bz), bz = fmaf((float)(c.z >> 16), r.az, r.bz);
+    tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
+}
 template <bool STATS>
 __device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, float tmin, float best_t, int node,
                                          int* stack, int stride, int& sp, TraceStats& st) {
     if (STATS) st.nodes++;
-    const float4 n0 = sc.nodes[4 * node + 0];
-    const float4 n1 = sc.nodes[4 * node + 1];
-    const float4 n2 = sc.nodes[4 * node + 2];
-    const float4 n3 = sc.nodes[4 * node + 3];
-    // child 0: lo = (n0.x n0.y n0.z) hi = (n0.w n1.x n1.y); child 1: lo = (n1.z n1.w n2.x) hi = (n2.y n2.z n2.w)
+    const uint4 n0 = sc.nodes[2 * node + 0];
+    const uint4 n1 = sc.nodes[2 * node + 1];
     const float tmax_pad = best_t * 1.0000004f;
-    float ax = fmaf(n0.x, r.idx, -r.oodx), bx = fmaf(n0.w, r.idx, -r.oodx);
-    float ay = fmaf(n0.y, r.idy, -r.oody), by = fmaf(n1.x, r.idy, -r.oody);
-    float az = fmaf(n0.z, r.idz, -r.oodz), bz = fmaf(n1.y, r.idz, -r.oodz);
-    const float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
-    ax = fmaf(n1.z, r.idx, -r.oodx), bx = fmaf(n2.y, r.idx, -r.oodx);
-    ay = fmaf(n1.w, r.idy, -r.oody), by = fmaf(n2.z, r.idy, -r.oody);
-    az = fmaf(n2.x, r.idz, -r.oodz), bz = fmaf(n2.w, r.idz, -r.oodz);
-    const float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
+    float t0n, t0f, t1n, t1f;
+    child_slab(n0, r, tmin, tmax_pad, t0n, t0f);
+    child_slab(n1, r, tmin, tmax_pad, t1n, t1f);
     const bool h0 = t0n <= t0f, h1 = t1n <= t1f;
-    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    const int c0 = (int)n0.w, c1 = (int)n1.w;
     if (h0 && h1) {
         const bool swap = t1n < t0n;
         stack[sp * stride] = swap ? c0 : c1;
@@ -480,7 +495,7 @@ __device__ __forceinline__ HitRec trace_closest(const DevScene& sc, const Ray& r
     closest_reset(best);
     loose_hits<STATS>(sc.loose_rec, sc.n_loose, ray, tmin, best, st);
     if (!sc.has_tree) return best.h;
-    const SlabRay r = slab_ray(ray);
+    const SlabRay r = slab_ray(sc, ray);
     int sp = 0;
     int node = hits_tree_bounds(sc, r, tmin, best.h.t) ? 0 : kTraversalDone;  // the root is always an inner node
     while (node != kTraversalDone) {

@@ -49,7 +49,11 @@ struct DevCamera {
 struct DevScene {
     // render tree (binned SAH, leaves <= 4): triangles, plus spheres/quads when a scene has too many of
     // them to test "loose"
-    const float4* nodes;        // 4 per inner node: child-pair boxes (inflated, rounded outward) + child ids
+    const uint4* nodes;         // 2 per inner node (32 B), one per child: {x, y, z, ref} with each axis word holding
+                                //   the child box's lo (low half) and hi (high half) plane on a 16-bit grid over the
+                                //   tree's bounds (rounded outward by at least a step), ref = child id: >= 0 inner
+                                //   node, < 0 leaf ~first_slot.  A node visit is two 16-byte fetches per lane
+                                //   instead of four: the kernels are bound by the vector L1's request rate.
     const float4* prims;        // 3 per leaf slot: tri {v0|meta, e1|rank, e2}; rank = position in the
                                 //   reference tree's in-order leaf sequence (decides equal-t ties)
     const float4* tri_shade;    // 3 per leaf slot: vertex normals n0 n1 n2; [0].w = material id bits
@@ -59,7 +63,8 @@ struct DevScene {
                                 //   persistent kernels stage these in LDS
     uint32_t n_loose;
     uint32_t has_tree;          // 0: no surface lives in the render tree (all are loose)
-    float tree_lo[3], tree_hi[3];  // bounds of the render tree (inflated like the node boxes)
+    float grid_lo[3], grid_step[3];  // the grid: plane q of axis a lies at grid_lo[a] + q * grid_step[a], q in
+                                     //   0 .. 65535; planes 0 and 65535 are the (inflated) bounds of the render tree
     const double* spheres;      // 4 per sphere: c.xyz r
     const double* sphere_gate;  // 6 per sphere: lo.xyz hi.xyz of the reference tree's leaf that holds it; read for
                                 //   negative radii only (their inverted bounding box adds nothing to the leaf's

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
     Ray ray;
     ray.o = {0., 0., 0.};
     ray.d = {0.f, 0.f, 1.f};
-    SlabRay sr = slab_ray(ray);
+    SlabRay sr = slab_ray(sc, ray);
     Closest best;
     closest_reset(best);
     Rng rng;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
                     closest_reset(best);
                     loose_hits<STATS, EXT>(uniform_recs(sc.loose_rec), sc.n_loose, ray, 0.001f, best, st);
                     if (sc.has_tree) {
-                        sr = slab_ray(ray);
+                        sr = slab_ray(sc, ray);
                         sp = 0;
                         // rays that never reach the tree's bounds are complete already: stay in the shade stage
                         node = hits_tree_bounds(sc, sr, 0.001f, best.h.t) ? 0 : kStageShade;

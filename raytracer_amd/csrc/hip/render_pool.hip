@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void render_pool_kernel(DevScene
     Ray ray;
     ray.o = {0., 0., 0.};
     ray.d = {0.f, 0.f, 1.f};
-    SlabRay sr = slab_ray(ray);
+    SlabRay sr = slab_ray(sc, ray);
     Closest best;
     closest_reset(best);
     Rng rng;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void render_pool_kernel(DevScene
                     if (STATS) n_segments++;
                     loose_hits<STATS>(lds_loose, sc.n_loose, r2, 0.001f, b2, st);
                     dest = 0;
-                    if (sc.has_tree && hits_tree_bounds(sc, slab_ray(r2), 0.001f, b2.h.t)) dest = 1;
+                    if (sc.has_tree && hits_tree_bounds(sc, slab_ray(sc, r2), 0.001f, b2.h.t)) dest = 1;
                     dp2 = (depth2 << kPixBits) | pix2;
                 }
                 rec_store(pool + 5 * s, r2, g2, thr2, dp2, b2.h, b2.rank);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64, RT_POOL_WAVES) void render_pool_kernel(DevScene
             n_fq += (exhausted ? sw_c : 0) - sw_b;
             if (src >= 0) {
                 ray = r2, rng = g2, thr = thr2, dp = dp2, best.h = h2, best.rank = rank2;
-                sr = slab_ray(ray);
+                sr = slab_ray(sc, ray);
                 sp = 0;
                 node = 0;  // the root; the record's ray reaches the tree's bounds (tested in the shade trip)
             } else if (dst >= 0) {
