@@ -301,3 +301,89 @@ def load_scene(path, aspect_ratio):
                            _num(cam.get("aperture") or 0.0), 1.0 if fd is not None else 0.0,
                            _num(fd) if fd is not None else 0.0], dtype=np.float64)
     return out.finish()
+
+
+# ---------------------------------------------------------------- scene/example.rs: the examples that draw no
+# random numbers — two-spheres (:208-234), cornell (:262-329), cornell-smoke (:331-403), earth (:405-438) —
+# restated independently of the product's generator (raytracer_amd/csrc/host/examples.cpp), so that
+# tests/test_examples.py can compare rt_example_scene's arrays with these bit for bit.
+def _make_box(a, b):
+    """make_box, surfaces.rs:542-590: the six quads (q, u, v) front, right, back, left, top, bottom."""
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    dx = np.array([hi[0] - lo[0], 0.0, 0.0])
+    dy = np.array([0.0, hi[1] - lo[1], 0.0])
+    dz = np.array([0.0, 0.0, hi[2] - lo[2]])
+    P = lambda x, y, z: np.array([x, y, z], dtype=np.float64)
+    return [(P(lo[0], lo[1], hi[2]), dx, dy), (P(hi[0], lo[1], hi[2]), -dz, dy), (P(hi[0], lo[1], lo[2]), -dx, dy),
+            (P(lo[0], lo[1], lo[2]), dz, dy), (P(lo[0], hi[1], hi[2]), dx, -dz), (P(lo[0], lo[1], lo[2]), dx, dz)]
+
+
+def _pad_box(lo, hi, delta=0.0001):
+    """Aabb::pad, trace.rs: an axis narrower than delta is widened to delta about its middle."""
+    lo, hi = lo.copy(), hi.copy()
+    for a in range(3):
+        if hi[a] - lo[a] < delta:
+            lo[a], hi[a] = lo[a] - delta / 2.0, hi[a] + delta / 2.0
+    return lo, hi
+
+
+def _turned_box(a, b, degrees, offset):
+    """Translated(Rotated(make_box(a, b), +y, degrees), offset) as world-space quads: Rotated turns about the
+    centroid of the box's bounding box — the merge of its quads' padded boxes (surfaces.rs:356-359, 507-517) —
+    and the hit point / normal are turned back (surfaces.rs:520-534), which is the same as turning the quads;
+    Translated then shifts them (surfaces.rs:480-491)."""
+    quads = _make_box(np.asarray(a, float), np.asarray(b, float))
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for q, u, v in quads:
+        far = q + u + v
+        blo, bhi = _pad_box(np.minimum(q, far), np.maximum(q, far))
+        lo, hi = np.minimum(lo, blo), np.maximum(hi, bhi)
+    centre = lo + 0.5 * (hi - lo)  # Aabb::centroid, trace.rs
+    rot = quat_rotation(np.array([0.0, 1.0, 0.0]), math.radians(degrees))
+    out = []
+    for q, u, v in quads:
+        p0 = quat_rotate_point(rot, centre, q) + offset
+        p1 = quat_rotate_point(rot, centre, q + u) + offset
+        p2 = quat_rotate_point(rot, centre, q + v) + offset
+        out.append((p0, p1 - p0, p2 - p0))
+    return out
+
+
+def example_scene(name):
+    """-> dict(camera=[fov, from, towards, aperture, focus or None], background, surfaces=[...], media=[...]).
+    A surface is ("sphere", centre, radius, material) or ("quad", q, u, v, material); a medium is
+    (boundary quads [(q, u, v)...], density, albedo); a material is (kind, albedo, param, texture, albedo2, scale)
+    with texture in {"solid", "uv_checker", "image"}."""
+    solid = lambda kind, albedo, param=0.0: (kind, tuple(albedo), param, "solid", (0.0, 0.0, 0.0), 0.0)
+    V = lambda *c: np.array(c, dtype=np.float64)
+    if name == "two-spheres":
+        checker = (LAMBERTIAN, (0.2, 0.3, 0.1), 0.0, "uv_checker", (0.9, 0.9, 0.9), 30.0)
+        return dict(camera=[20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 0.0, None], background=(0.7, 0.8, 1.0),
+                    surfaces=[("sphere", V(0, -10, 0), 10.0, checker), ("sphere", V(0, 10, 0), 10.0, checker)], media=[])
+    if name == "earth":
+        # ./scenes/res/earth.png is not in the reference's repository: earth_texture() falls back to the solid
+        # colour (0, 1, 1) (example.rs:430-438); the two Rotated wrappers turn a sphere about its own centre
+        globe = (LAMBERTIAN, (0.0, 1.0, 1.0), 0.0, "image", (0.0, 0.0, 0.0), 1.0)
+        return dict(camera=[20.0, (0.0, 0.0, 12.0), (0.0, 0.0, 0.0), 0.0, None], background=(0.7, 0.8, 1.0),
+                    surfaces=[("sphere", V(0, 0, 0), 2.0, globe)], media=[])
+    if name in ("cornell", "cornell-smoke"):
+        smoke = name == "cornell-smoke"
+        red, white, green = solid(LAMBERTIAN, (0.65, 0.05, 0.05)), solid(LAMBERTIAN, (0.73, 0.73, 0.73)), solid(LAMBERTIAN, (0.12, 0.45, 0.15))
+        light = solid(DIFFUSE_LIGHT, (7.0, 7.0, 7.0) if smoke else (15.0, 15.0, 15.0))
+        lq = (V(113, 554, 127), V(330, 0, 0), V(0, 0, 305)) if smoke else (V(343, 554, 332), V(-130, 0, 0), V(0, 0, -105))
+        surfaces = [("quad", V(555, 0, 0), V(0, 555, 0), V(0, 0, 555), green),
+                    ("quad", V(0, 0, 0), V(0, 555, 0), V(0, 0, 555), red),
+                    ("quad", *lq, light),
+                    ("quad", V(0, 555, 0), V(555, 0, 0), V(0, 0, 555), white),
+                    ("quad", V(0, 0, 0), V(555, 0, 0), V(0, 0, 555), white),
+                    ("quad", V(0, 0, 555), V(555, 0, 0), V(0, 555, 0), white)]
+        box1 = _turned_box((0.0, 0.001, 0.0), (165.0, 333.0, 165.0), 15.0, V(265, 0, 295))
+        box2 = _turned_box((0.0, 0.001, 0.0), (165.0, 165.0, 165.0), -18.0, V(130, 0, 65))
+        media = []
+        if smoke:  # ConstantMedium::new(box, 0.01, colour), example.rs:387-398
+            media = [(box1, 0.01, (0.0, 0.0, 0.0)), (box2, 0.01, (1.0, 1.0, 1.0))]
+        else:
+            surfaces += [("quad", q, u, v, white) for q, u, v in box1 + box2]
+        return dict(camera=[40.0, (278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 0.0, None], background=(0.0, 0.0, 0.0),
+                    surfaces=surfaces, media=media)
+    raise ValueError(f"{name}: not one of the examples that draw no random numbers")

@@ -59,7 +59,12 @@ void add_quad(HostScene& hs, V3 q, V3 u, V3 v, int material) {
 void add_box(HostScene& hs, V3 a, V3 b, int material, double degrees, V3 offset, bool as_surfaces = true) {
     const V3 lo = vmin(a, b), hi = vmax(a, b);
     const V3 dx{hi.x - lo.x, 0, 0}, dy{0, hi.y - lo.y, 0}, dz{0, 0, hi.z - lo.z};
-    const V3 centre = 0.5 * (lo + hi);  // the quads' boxes are padded symmetrically: same centroid
+    // Rotated::new turns about Aabb::centroid (min + 0.5 * (max - min), trace.rs:169-174) of the box's bounding
+    // box: the merge of its quads' boxes, each padded by 0.0001 where it is flat (Quad::bounding_box,
+    // surfaces.rs:356-359; Aabb::pad, trace.rs:116-129) — the box's own extent widened by 0.00005 on every side
+    const V3 pad{0.00005, 0.00005, 0.00005};
+    const V3 blo = lo - pad, bhi = hi + pad;
+    const V3 centre = blo + 0.5 * (bhi - blo);
     const Quat rot = Quat::rotation(V3{0, 1, 0}, degrees * 0.017453292519943295);
     auto put = [&](V3 q, V3 u, V3 v) {
         const V3 p0 = rotate_point(rot, centre, q) + offset;

@@ -114,6 +114,54 @@ def test_examples_camera_matches_oracle_and_unsupported_names_are_refused(ra, re
         ra.example_scene("teapot", 1.5)
 
 
+@pytest.mark.parametrize("name", ["two-spheres", "earth", "cornell", "cornell-smoke"])
+def test_deterministic_examples_match_the_independent_restatement(ra, name):
+    """The four examples that draw no random numbers, restated in oracle/loader_ref.py from example.rs on its own
+    (make_box, the Rotated/Translated wrappers turned into world-space quads, the materials, the media): the
+    generator's arrays must hold the very same doubles, surface by surface in the reference's order."""
+    from oracle import loader_ref as L
+
+    want = L.example_scene(name)
+    d = ra.example_scene(name, 1.25)
+    mats, sph, quads, surf, media = d.materials, d.spheres, d.quads, d.surfaces, d.media
+    tex_names = {ra.RT_TEX_SOLID: "solid", ra.RT_TEX_UV_CHECKER: "uv_checker", ra.RT_TEX_IMAGE: "image"}
+
+    def material(i):
+        m = mats[i]
+        return (int(m["kind"]), tuple(m["albedo"]), float(m["param"]), tex_names[int(m["texture"])],
+                tuple(m["albedo2"]) if m["texture"] != ra.RT_TEX_SOLID else (0.0, 0.0, 0.0),
+                float(m["tex_scale"]) if m["texture"] != ra.RT_TEX_SOLID else 0.0)
+
+    assert np.array_equal(d.background, want["background"])
+    shown = [s for s in surf if s["type"] != ra.api.RT_SURF_QUAD + 1]  # media are listed after the surfaces
+    assert len(shown) == len(want["surfaces"]) and len(media) == len(want["media"])
+    for s, w in zip(shown, want["surfaces"]):
+        if w[0] == "sphere":
+            assert s["type"] == ra.RT_SURF_SPHERE
+            g = sph[s["index"]]
+            assert np.array_equal(g["center"], w[1]) and g["radius"] == w[2] and not g["moving"]
+            assert material(g["material"]) == w[3]
+        else:
+            assert s["type"] == ra.RT_SURF_QUAD
+            g = quads[s["index"]]
+            assert np.array_equal(g["q"], w[1]) and np.array_equal(g["u"], w[2]) and np.array_equal(g["v"], w[3]), (name, s["index"])
+            assert material(g["material"]) == w[4]
+    for k, (box, density, albedo) in enumerate(want["media"]):
+        m = media[k]
+        assert m["boundary"] == ra.RT_SURF_QUAD and m["count"] == 6 and m["density"] == density
+        assert mats[m["material"]]["kind"] == 4 and tuple(mats[m["material"]]["albedo"]) == albedo
+        for j, (q, u, v) in enumerate(box):
+            g = quads[m["first"] + j]
+            assert np.array_equal(g["q"], q) and np.array_equal(g["u"], u) and np.array_equal(g["v"], v), (name, k, j)
+        assert surf[len(shown) + k]["type"] == 3 and surf[len(shown) + k]["index"] == k
+    if name == "earth":  # the missing earth.png: an image texture without pixels shades the fallback colour
+        assert len(d.images) == 1 and d.images[0].size == 0
+    # the camera: Camera::builder defaults (no aperture, focus distance |from - towards|), camera.rs:43-74
+    fov, frm, to, aperture, focus = want["camera"]
+    assert aperture == 0.0 and focus is None and d.camera.lens_radius == 0.0
+    assert CAMERAS[name](1.25)[:8] == [fov, 1.25, *frm, *to]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,w,h,sn", [("one-weekend", 150, 100, 4), ("cornell", 96, 96, 5),
                                          ("random-spheres", 150, 100, 4), ("two-spheres", 120, 80, 4),
