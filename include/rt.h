@@ -258,6 +258,20 @@ int rt_tonemap_rgb8(const float* rgb_sum, uint32_t width, uint32_t height, uint6
 int rt_tonemap_rgb8_device(const float* d_rgb_sum, uint32_t width, uint32_t height, uint64_t n_samples,
                            uint8_t* d_out, void* stream);
 
+/* ---- several GPUs of one process: the path's one exchange step ----
+ * No counterpart in the reference (its pixels are shared memory under rayon, main.rs:150): with the strata of a
+ * frame sharded over GPUs (rt_render_params.stratum_begin / stratum_step), the per-GPU radiance sums are added
+ * onto one GPU by ONE collective, an RCCL sum-reduce over xGMI.  One process per GPU does the same through its
+ * own communicator (bench.py: torch.distributed); these calls serve one process that drives several GPUs (the CLI's
+ * --gpus N).  librccl is loaded at the first rt_group_create, not with the library. */
+typedef struct rt_group rt_group;
+/* A communicator clique over the `n` HIP devices `devices` of this process (ncclCommInitAll). */
+int rt_group_create(const int* devices, int n, rt_group** out);
+/* d_bufs[i] (count floats in device i's memory) summed over i into d_bufs[root], in place; enqueued on streams[i]
+ * (streams == NULL: every device's default stream) and not awaited: synchronise the root's stream before reading. */
+int rt_group_reduce_sum(rt_group* group, float* const* d_bufs, size_t count, int root, void* const* streams);
+void rt_group_destroy(rt_group* group);
+
 /* ---- image output: replaces the png crate use at main.rs:192-200 (RGB8, row 0 = top) ---- */
 int rt_write_png(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height);
 

@@ -123,34 +123,46 @@ def _axis(a):
 def read_obj_first_model(path):
     """tobj::load_obj_buf, default options, first model: f32 positions re-indexed in order of first use."""
     opener = gzip.open if path.endswith(".gz") else open
-    pos, faces = [], []
+    pos, nrm, faces, nfaces = [], [], [], []
     with opener(path, "rt") as f:
         for line in f:
             if line.startswith("v "):
                 pos.append(line.split()[1:4])
-            elif line.startswith("f "):
-                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
-                if len(idx) != 3:
-                    raise ValueError("only triangles are supported")
-                faces.append(idx)
-            elif line[:2] in ("o ", "g ") and faces:
-                break
             elif line.startswith("vn "):
-                raise ValueError("oracle loader: OBJ normals not supported (no reference scene has them)")
+                nrm.append(line.split()[1:4])
+            elif line.startswith("f "):
+                toks = [tok.split("/") for tok in line.split()[1:]]
+                if len(toks) != 3:
+                    raise ValueError("only triangles are supported")
+                faces.append([int(t[0]) for t in toks])
+                if len(toks[0]) == 3 and toks[0][2]:
+                    nfaces.append([int(t[2]) for t in toks])
+            elif line[:2] in ("o ", "g ") and faces:
+                break  # only the first model is used (load.rs:225-229)
     pos32 = np.array(pos, dtype=np.float32)  # numpy parses decimal -> f32 with correct rounding
-    faces = np.array(faces, dtype=np.int64)
-    faces = np.where(faces < 0, faces + len(pos32), faces - 1)
-    flat = faces.reshape(-1)
-    _, first = np.unique(flat, return_index=True)
-    order = flat[np.sort(first)]  # vertex ids in order of first use
-    remap = np.full(len(pos32), -1, dtype=np.int64)
-    remap[order] = np.arange(len(order))
-    return pos32[order].astype(np.float64), remap[faces]
+
+    def first_use(ids, n):
+        ids = np.array(ids, dtype=np.int64)
+        ids = np.where(ids < 0, ids + n, ids - 1)
+        flat = ids.reshape(-1)
+        _, first = np.unique(flat, return_index=True)
+        order = flat[np.sort(first)]  # ids in order of first use (export_faces_multi_index)
+        remap = np.full(n, -1, dtype=np.int64)
+        remap[order] = np.arange(len(order))
+        return order, remap[ids]
+
+    order, faces = first_use(faces, len(pos32))
+    normals = None
+    if nfaces:  # normals are exported in order of THEIR first use, by their own index map
+        nrm32 = np.array(nrm, dtype=np.float32)
+        norder, _ = first_use(nfaces, len(nrm32))
+        normals = nrm32[norder].astype(np.float64)
+    return pos32[order].astype(np.float64), faces, normals
 
 
 def load_mesh(path, transforms):
     """load.rs:202-313 + Mesh::new surfaces.rs:146-169.  Returns (v[T,3,3], n[T,3,3])."""
-    verts, faces = read_obj_first_model(path)
+    verts, faces, given_normals = read_obj_first_model(path)
     mesh_origin = compute_mesh_center(verts)
     verts = verts - mesh_origin
     for t in transforms or []:
@@ -172,6 +184,14 @@ def load_mesh(path, transforms):
         else:
             raise ValueError(f"unknown transform {k}")
     v0, v1, v2 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    if given_normals is not None:
+        # Mesh::new_with_normals (load.rs:303-311): the file's normals as they are — no transform turns them — and
+        # looked up by the POSITION index (surfaces.rs:231-243)
+        if len(given_normals) < len(verts):
+            raise ValueError("mesh has fewer normals than vertices")
+        tri_v = np.stack([v0, v1, v2], axis=1)
+        tri_n = np.stack([given_normals[faces[:, 0]], given_normals[faces[:, 1]], given_normals[faces[:, 2]]], axis=1)
+        return tri_v, tri_n, mesh_origin
     e1, e2 = v1 - v0, v0 - v2
     # cross(e2, e1), component formulas of geom.rs:182-188
     fn = np.stack([e2[:, 1] * e1[:, 2] - e2[:, 2] * e1[:, 1],

@@ -26,7 +26,7 @@ RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_UV_CHECKER, RT_TEX_MARBLE, RT_TEX_IMAGE = 0
 EXPORTED_SYMBOLS = [
     "rt_load_scene", "rt_example_scene", "rt_scene_desc_free", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_leaf_order", "rt_render_device", "rt_render_device_noalloc", "rt_render", "rt_primary_hits", "rt_tonemap_rgb8",
-    "rt_tonemap_rgb8_device", "rt_write_png", "rt_set_verbose", "rt_last_error", "rt_version",
+    "rt_tonemap_rgb8_device", "rt_group_create", "rt_group_reduce_sum", "rt_group_destroy", "rt_write_png", "rt_set_verbose", "rt_last_error", "rt_version",
 ]
 
 
@@ -182,6 +182,12 @@ def lib() -> C.CDLL:
     L.rt_tonemap_rgb8.restype = i32
     L.rt_tonemap_rgb8_device.argtypes = [vp, u32, u32, u64, vp, vp]
     L.rt_tonemap_rgb8_device.restype = i32
+    L.rt_group_create.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    L.rt_group_create.restype = i32
+    L.rt_group_reduce_sum.argtypes = [vp, C.POINTER(vp), C.c_size_t, i32, C.POINTER(vp)]
+    L.rt_group_reduce_sum.restype = i32
+    L.rt_group_destroy.argtypes = [vp]
+    L.rt_group_destroy.restype = None
     L.rt_write_png.argtypes = [C.c_char_p, vp, u32, u32]
     L.rt_write_png.restype = i32
     L.rt_set_verbose.argtypes = [i32]

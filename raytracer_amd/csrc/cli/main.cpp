@@ -1,6 +1,7 @@
 // `raytracer` — command line of the reference (clap derive, main.rs:23-66) over the C ABI in include/rt.h.
 // Same flag names, defaults and conflict rule; same stderr "Done in …" line (main.rs:190) and RGB8 PNG
-// (main.rs:192-200).  Extra flags: --gpus N, --kernel persistent|wavefront|pool, --sampler direct|reference, --dump-primary FILE, --json.
+// (main.rs:192-200).  Extra flags: --gpus N, --reduce rccl|host, --progressive SECS, --kernel persistent|wavefront|pool,
+// --sampler direct|reference, --dump-primary FILE, --json.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -10,6 +11,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "../../../include/rt.h"
 
@@ -29,6 +32,8 @@ struct Opt {
     int gpus = 1;
     int kernel = RT_KERNEL_PERSISTENT;
     int sampler = RT_SAMPLER_DIRECT;
+    bool reduce_rccl = true;    // --gpus N: sum the per-GPU framebuffers with one RCCL reduce (else over PCIe on the host)
+    double progressive = -1.0;  // >= 0: write the running image every so many seconds
 };
 
 [[noreturn]] void usage_error(const std::string& m) {
@@ -48,11 +53,15 @@ void help() {
         "      --aspect-ratio <ASPECT_RATIO>  Output image aspect ratio [default: 1.5]\n"
         "      --seed <SEED>                  Seed to use for RNG\n"
         "      --scene <SCENE>                A scene file to load from configuration\n"
-        "      --example <EXAMPLE>            An example scene from the book, generated at random: one-weekend\n"
-        "                                     (default without --scene) or cornell; drawn from --seed\n"
+        "      --example <EXAMPLE>            An example scene from the book: one-weekend (default without --scene),\n"
+        "                                     random-spheres, two-spheres, two-perlin, earth, cornell, cornell-smoke,\n"
+        "                                     final-scene; the random ones are drawn from --seed\n"
         "      --no-progress                  Disables the progress block (shown for long renders, once a second)\n"
         "      --no-bvh                       Disables the use of the bvh acceleration structure\n"
         "      --gpus <N>                     Shard the strata over N GPUs [default: 1]\n"
+        "      --reduce <rccl|host>           How the GPUs' framebuffers are summed: one RCCL reduce over xGMI\n"
+        "                                     [default], or copies over PCIe added on the host\n"
+        "      --progressive <SECS>           Write the image so far to --output every SECS seconds while rendering\n"
         "      --kernel <persistent|wavefront|pool>\n"
         "      --sampler <direct|reference>   Unit-sphere/disk sampling: loop-free maps or the reference's rejection loops\n"
         "      --dump-primary <FILE>          Write the f64 primary-hit AOV (int32 ids, then f64 t) and exit\n"
@@ -101,6 +110,17 @@ Opt parse(int argc, char** argv) {
         else if (key == "--json") o.json = true;
         else if (key == "--gpus") o.gpus = (int)to_size(need(i, "--gpus"), "--gpus");
         else if (key == "--dump-primary") o.dump_primary = need(i, "--dump-primary");
+        else if (key == "--reduce") {
+            std::string v = need(i, "--reduce");
+            if (v == "rccl") o.reduce_rccl = true;
+            else if (v == "host") o.reduce_rccl = false;
+            else usage_error("invalid value '" + v + "' for '--reduce'");
+        } else if (key == "--progressive") {
+            std::string v = need(i, "--progressive");
+            char* end = nullptr;
+            o.progressive = std::strtod(v.c_str(), &end);
+            if (*end || v.empty() || !(o.progressive >= 0.0)) usage_error("invalid value '" + v + "' for '--progressive'");
+        }
         else if (key == "--kernel") {
             std::string v = need(i, "--kernel");
             if (v == "persistent") o.kernel = RT_KERNEL_PERSISTENT;
@@ -176,16 +196,33 @@ int main(int argc, char** argv) {
     const auto render_start = std::chrono::steady_clock::now();
 
     // Long jobs are rendered in batches of strata so that the progress block of progress.rs:63-97 (elapsed,
-    // remaining, samples/sec, remaining pixels; once a second) can be shown; short ones go in one launch.
+    // remaining, samples/sec, remaining pixels; once a second) can be shown and, with --progressive, the image so
+    // far written; short ones go in one launch.
     const double total_samples = (double)width * (double)height * (double)sn * (double)sn;
     const uint32_t n_strata = sn * sn;
-    const uint32_t batches = (!o.no_progress && total_samples > 8e9) ? std::min<uint32_t>(32u, std::max(1u, n_strata / (uint32_t)o.gpus)) : 1u;
-    std::vector<float> sum(3 * width * height, 0.f);
-    std::vector<std::vector<float>> parts((size_t)o.gpus, std::vector<float>(3 * width * height));
+    const bool batched = o.progressive >= 0.0 || (!o.no_progress && total_samples > 8e9);
+    const uint32_t batches = batched ? std::min<uint32_t>(32u, std::max(1u, n_strata / (uint32_t)o.gpus)) : 1u;
+    const size_t n_values = 3 * width * height;
+    std::vector<float> sum(n_values, 0.f), part(n_values);
+    // every GPU renders its strata of the batch into a framebuffer in its own memory
+    std::vector<float*> d_fb((size_t)o.gpus, nullptr);
+    for (int g = 0; g < o.gpus; ++g)
+        if (hipSetDevice(g) != hipSuccess || hipMalloc((void**)&d_fb[(size_t)g], n_values * sizeof(float)) != hipSuccess) {
+            std::fprintf(stderr, "Error: could not allocate the framebuffer on GPU %d\n", g);
+            return 1;
+        }
+    rt_group* group = nullptr;
+    if (o.gpus > 1 && o.reduce_rccl) {
+        std::vector<int> devices((size_t)o.gpus);
+        for (int g = 0; g < o.gpus; ++g) devices[(size_t)g] = g;
+        if (rt_group_create(devices.data(), o.gpus, &group)) return die("");
+    }
     std::vector<rt_stats> stats((size_t)o.gpus);
     double kernel_ms_total = 0;
-    auto last_report = start;
+    uint64_t samples_done = 0;  // per pixel
+    auto last_report = start, last_image = start;
     bool reported = false;
+    uint32_t partial_images = 0;
     for (uint32_t b = 0; b < batches; ++b) {
         std::vector<int> rc((size_t)o.gpus, 0);
         std::vector<std::string> errs((size_t)o.gpus);
@@ -196,7 +233,7 @@ int main(int argc, char** argv) {
                 p.width = (uint32_t)width, p.height = (uint32_t)height, p.sn = sn, p.max_depth = max_depth;
                 p.seed = seed, p.kernel = o.kernel, p.sampler = o.sampler;
                 p.stratum_begin = b * (uint32_t)o.gpus + (uint32_t)g, p.stratum_step = batches * (uint32_t)o.gpus;
-                rc[(size_t)g] = rt_render(scenes[(size_t)g], &p, parts[(size_t)g].data(), &stats[(size_t)g]);
+                rc[(size_t)g] = rt_render_device(scenes[(size_t)g], &p, d_fb[(size_t)g], nullptr, &stats[(size_t)g]);
                 if (rc[(size_t)g]) errs[(size_t)g] = rt_last_error();
             });
         }
@@ -207,12 +244,32 @@ int main(int argc, char** argv) {
                 std::fprintf(stderr, "Error: render on GPU %d: %s\n", g, errs[(size_t)g].c_str());
                 return 1;
             }
-            for (size_t i = 0; i < sum.size(); ++i) sum[i] += parts[(size_t)g][i];
             batch_ms = std::fmax(batch_ms, stats[(size_t)g].kernel_ms);
+            samples_done += stats[(size_t)g].samples / ((uint64_t)width * height);
         }
         kernel_ms_total += batch_ms;
+        // the exchange step: the GPUs' sums onto GPU 0 with one RCCL reduce, or one copy per GPU over PCIe
+        if (group && rt_group_reduce_sum(group, d_fb.data(), n_values, 0, nullptr)) return die("");
+        for (int g = 0; g < (group ? 1 : o.gpus); ++g) {
+            if (hipSetDevice(g) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(part.data(), d_fb[(size_t)g], n_values * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+                std::fprintf(stderr, "Error: could not read the framebuffer of GPU %d\n", g);
+                return 1;
+            }
+            for (size_t i = 0; i < n_values; ++i) sum[i] += part[i];
+        }
         const auto now = std::chrono::steady_clock::now();
-        if (batches > 1 && b + 1 < batches && std::chrono::duration<double>(now - last_report).count() >= 1.0) {
+        if (o.progressive >= 0.0 && b + 1 < batches && std::chrono::duration<double>(now - last_image).count() >= o.progressive) {
+            // the image so far: the strata rendered up to here are a stratified subset of every pixel's
+            last_image = now;
+            std::vector<uint8_t> rgb(n_values);
+            if (rt_tonemap_rgb8(sum.data(), (uint32_t)width, (uint32_t)height, samples_done, rgb.data())) return die("tonemap");
+            const std::string tmp = o.output + ".part";
+            if (rt_write_png(tmp.c_str(), rgb.data(), (uint32_t)width, (uint32_t)height) || std::rename(tmp.c_str(), o.output.c_str()))
+                return die("could not write image");
+            ++partial_images;
+        }
+        if (!o.no_progress && batches > 1 && b + 1 < batches && std::chrono::duration<double>(now - last_report).count() >= 1.0) {
             last_report = now;
             const double elapsed = std::chrono::duration<double>(now - start).count();
             const double done = (double)(b + 1) / (double)batches;
@@ -231,6 +288,10 @@ int main(int argc, char** argv) {
                          e, r, total_samples * done / render_elapsed, (double)width * (double)height * (1.0 - done));
         }
     }
+    if (o.progressive >= 0.0) std::fprintf(stderr, "wrote %u partial image%s to %s\n", partial_images, partial_images == 1 ? "" : "s", o.output.c_str());
+    rt_group_destroy(group);
+    for (int g = 0; g < o.gpus; ++g)
+        if (hipSetDevice(g) == hipSuccess) (void)hipFree(d_fb[(size_t)g]);
 
     std::vector<uint8_t> rgb(3 * width * height);
     if (rt_tonemap_rgb8(sum.data(), (uint32_t)width, (uint32_t)height, (uint64_t)sn * sn, rgb.data())) return die("tonemap");
@@ -241,8 +302,8 @@ int main(int argc, char** argv) {
     if (rt_write_png(o.output.c_str(), rgb.data(), (uint32_t)width, (uint32_t)height)) return die("could not write image");
     if (o.json) {
         const double kernel_ms = kernel_ms_total;
-        std::printf("{\"samples\": %.0f, \"wall_s\": %.4f, \"kernel_ms\": %.3f, \"msamples_per_s\": %.3f, \"gpus\": %d}\n",
-                    rays, elapsed, kernel_ms, rays / (kernel_ms * 1e3), o.gpus);
+        std::printf("{\"samples\": %.0f, \"wall_s\": %.4f, \"kernel_ms\": %.3f, \"msamples_per_s\": %.3f, \"gpus\": %d, \"reduce\": \"%s\"}\n",
+                    rays, elapsed, kernel_ms, rays / (kernel_ms * 1e3), o.gpus, o.gpus > 1 ? (o.reduce_rccl ? "rccl" : "host") : "none");
     }
     for (rt_scene* s : scenes) rt_scene_destroy(s);
     rt_scene_desc_free(desc);

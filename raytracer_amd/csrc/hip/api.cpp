@@ -35,6 +35,10 @@ int set_error(const std::string& m) {
     return 1;
 }
 
+}  // namespace
+int rt_set_error_message(const std::string& m) { return set_error(m); }  // for the library's other translation units
+namespace {
+
 struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };

@@ -228,3 +228,31 @@ def test_render_tree_depth_is_capped_and_small_prims_move_into_the_tree(ra, tmp_
     assert 41 <= deep.render_depth <= 56  # SAH alone would go ~1500 levels deep on this cluster
     many = ra.Scene(ra.load_scene(synth.many_prims(tmp_path), 1.5), ra.RT_DEVICE_NONE).info()
     assert many.n_loose == 0 and many.n_surfaces == 1 + 28 + 2 + 5 + 200
+
+
+def test_obj_normals_and_first_model_only(ra, tmp_path):
+    """An OBJ with `vn` normals and two objects (load.rs:225-229, 300-312): the loader takes the first
+    model only, uses the file's normals as they are — looked up by position index (surfaces.rs:231-243), not turned
+    by the rotate transform, which moves vertices only — and agrees with the independent loader bit for bit."""
+    obj = ("o first\n"
+           "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0.25\n"
+           "vn 0 0 1\nvn 0.1 0 0.9\nvn 0 0.2 0.8\nvn -0.3 0 0.7\n"
+           "f 1//1 2//2 3//3\nf 1//1 3//3 4//4\n"
+           "o second\n"
+           "v 5 5 5\nv 6 5 5\nv 6 6 5\nvn 1 0 0\n"
+           "f 5//5 6//5 7//5\n")
+    (tmp_path / "m.obj").write_text(obj)
+    (tmp_path / "s.yaml").write_text(
+        "camera:\n  fov: 40\n  from: [0, 0, 5]\n  towards: [0, 0, 0]\n"
+        "scene:\n  background: [0.5, 0.5, 0.5]\n  surfaces:\n"
+        "    - type: mesh\n      path: m.obj\n      material: {type: lambertian, albedo: [0.5, 0.5, 0.5]}\n"
+        "      transform:\n        - {type: rotate, axis: y, angle: 30}\n        - {type: translate, dir: [0, 1, 0]}\n")
+    d = ra.load_scene(str(tmp_path / "s.yaml"), 1.0)
+    f = loader_ref.load_scene(str(tmp_path / "s.yaml"), 1.0)
+    tri = d.triangles
+    assert len(tri) == 2 and len(f.triangles) == 2                                   # the second object is not loaded
+    assert np.array_equal(tri["v"].reshape(-1, 9), f.triangles[:, :9])
+    assert np.array_equal(tri["n"].reshape(-1, 9), f.triangles[:, 9:18])
+    want = np.array([[0, 0, 1], [0.1, 0, 0.9], [0, 0.2, 0.8], [-0.3, 0, 0.7]], dtype=np.float32).astype(np.float64)
+    assert np.array_equal(tri["n"][0], want[[0, 1, 2]]) and np.array_equal(tri["n"][1], want[[0, 2, 3]])
+    assert not np.allclose(tri["v"][0][1], [1, 0, 0])                                # the vertices did turn
