@@ -129,7 +129,10 @@ typedef struct rt_scene_desc {
     size_t n_surfaces;
     double background[3];
     rt_camera camera;
-    int32_t use_bvh; /* 0 = one leaf holding every surface (--no-bvh, main.rs:60-65, scene/mod.rs:61-65) */
+    int32_t use_bvh; /* 0 = one leaf holding every surface (--no-bvh, main.rs:60-65, scene/mod.rs:61-65); 1 = trees
+                      * built on the host; 2 = as 1, but the tree the render kernels traverse is built on the GPU
+                      * (same binned-SAH criteria, level by level; the environment's RT_BUILD=device asks for the same).
+                      * The reference-topology tree (bvh.rs:131-234: tie ranks, parity kernel) is always a host build */
     int32_t _pad;
     const rt_perlin* perlin; /* noise tables the MARBLE textures refer to (may be null when n_perlin == 0) */
     size_t n_perlin;
@@ -143,6 +146,7 @@ typedef struct rt_scene_desc {
 
 /* Parses the scene YAML, loads OBJ(.gz) meshes, bakes transforms, builds the camera for
  * `aspect_ratio`.  *out is owned by the library; release with rt_scene_desc_free. */
+/* use_bvh: 0, 1 or 2 as rt_scene_desc.use_bvh says. */
 int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_scene_desc** out);
 
 /* Procedural example scenes: replaces Example::from_str + Example::scene (scene/example.rs:53-79) for all
@@ -174,7 +178,8 @@ typedef struct rt_scene_info {
     uint64_t render_nodes;
     uint32_t render_depth, render_max_leaf;
     uint32_t n_loose;       /* spheres + quads tested by every ray before traversal */
-    uint32_t _pad;
+    uint32_t device_build;  /* 1 if the render tree was built on the GPU */
+    double render_build_ms; /* the render tree's build alone (it runs beside the reference-topology build) */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* info);
 

@@ -90,7 +90,8 @@ class RtSceneInfo(C.Structure):
     _fields_ = [("n_surfaces", C.c_uint64), ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64),
                 ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32), ("device_bytes", C.c_uint64),
                 ("build_ms", C.c_double), ("render_nodes", C.c_uint64), ("render_depth", C.c_uint32),
-                ("render_max_leaf", C.c_uint32), ("n_loose", C.c_uint32), ("_pad", C.c_uint32)]
+                ("render_max_leaf", C.c_uint32), ("n_loose", C.c_uint32), ("device_build", C.c_uint32),
+                ("render_build_ms", C.c_double)]
 
 
 class RtRenderParams(C.Structure):
@@ -238,7 +239,7 @@ class SceneDesc:
             setattr(d, "n_" + name, len(a))
         d.background = (C.c_double * 3)(*background)
         d.camera = camera
-        d.use_bvh = 1 if use_bvh else 0
+        d.use_bvh = _bvh_mode(use_bvh)
         arrs["perlin"] = np.ascontiguousarray(perlin if perlin is not None else np.zeros(0, PERLIN_DTYPE), dtype=PERLIN_DTYPE)
         d.perlin = C.cast(arrs["perlin"].ctypes.data, C.POINTER(RtPerlin))
         d.n_perlin = len(arrs["perlin"])
@@ -299,17 +300,24 @@ class SceneDesc:
             pass
 
 
-def load_scene(path: str, aspect_ratio: float, use_bvh: bool = True) -> SceneDesc:
+def _bvh_mode(use_bvh) -> int:
+    """False / True as the reference's flag; "device" (or 2) additionally builds the render tree on the GPU."""
+    if use_bvh == "device" or use_bvh == 2:
+        return 2
+    return 1 if use_bvh else 0
+
+
+def load_scene(path: str, aspect_ratio: float, use_bvh=True) -> SceneDesc:
     """scene::load_scene(path, aspect_ratio, use_bvh) — load.rs:39-160."""
     out = C.POINTER(RtSceneDesc)()
-    _check(lib().rt_load_scene(os.fsencode(path), float(aspect_ratio), 1 if use_bvh else 0, C.byref(out)))
+    _check(lib().rt_load_scene(os.fsencode(path), float(aspect_ratio), _bvh_mode(use_bvh), C.byref(out)))
     return SceneDesc(out)
 
 
 def example_scene(name: str, aspect_ratio: float, seed: int = 0x5EED5EED, use_bvh: bool = True) -> SceneDesc:
     """Example::scene — scene/example.rs:53-79 (all eight example names)."""
     out = C.POINTER(RtSceneDesc)()
-    _check(lib().rt_example_scene(name.encode(), float(aspect_ratio), int(seed), 1 if use_bvh else 0, C.byref(out)))
+    _check(lib().rt_example_scene(name.encode(), float(aspect_ratio), int(seed), _bvh_mode(use_bvh), C.byref(out)))
     return SceneDesc(out)
 
 

@@ -28,7 +28,7 @@ struct Opt {
     double aspect_ratio = 1.5;
     uint64_t seed = 0;
     std::string scene, example, dump_primary;
-    bool no_progress = false, no_bvh = false, json = false;
+    bool no_progress = false, no_bvh = false, json = false, device_build = false;
     int gpus = 1;
     int kernel = RT_KERNEL_PERSISTENT;
     int sampler = RT_SAMPLER_DIRECT;
@@ -58,6 +58,7 @@ void help() {
         "                                     final-scene; the random ones are drawn from --seed\n"
         "      --no-progress                  Disables the progress block (shown for long renders, once a second)\n"
         "      --no-bvh                       Disables the use of the bvh acceleration structure\n"
+        "      --device-build                 Builds the tree the render kernels traverse on the GPU (default: host)\n"
         "      --gpus <N>                     Shard the strata over N GPUs [default: 1]\n"
         "      --reduce <rccl|host>           How the GPUs' framebuffers are summed: one RCCL reduce over xGMI\n"
         "                                     [default], or copies over PCIe added on the host\n"
@@ -107,6 +108,7 @@ Opt parse(int argc, char** argv) {
         else if (key == "--example") o.example = need(i, "--example"), o.has_example = true;
         else if (key == "--no-progress") o.no_progress = true;
         else if (key == "--no-bvh") o.no_bvh = true;
+        else if (key == "--device-build") o.device_build = true;
         else if (key == "--json") o.json = true;
         else if (key == "--gpus") o.gpus = (int)to_size(need(i, "--gpus"), "--gpus");
         else if (key == "--dump-primary") o.dump_primary = need(i, "--dump-primary");
@@ -160,9 +162,10 @@ int main(int argc, char** argv) {
     rt_scene_desc* desc = nullptr;
     // TracerOpt::scene, main.rs:96-107: a scene file if given, else the example (default one-weekend)
     const uint64_t scene_seed = o.has_seed ? o.seed : 0x5eed5eedull;
+    const int bvh_mode = o.no_bvh ? 0 : (o.device_build ? 2 : 1);
     if (o.has_scene) {
-        if (rt_load_scene(o.scene.c_str(), aspect, o.no_bvh ? 0 : 1, &desc)) return die("");
-    } else if (rt_example_scene(o.has_example ? o.example.c_str() : "one-weekend", aspect, scene_seed, o.no_bvh ? 0 : 1,
+        if (rt_load_scene(o.scene.c_str(), aspect, bvh_mode, &desc)) return die("");
+    } else if (rt_example_scene(o.has_example ? o.example.c_str() : "one-weekend", aspect, scene_seed, bvh_mode,
                                 &desc)) {
         return die("");
     }

@@ -269,11 +269,64 @@ void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
     s.info.max_leaf_size = bvh.max_leaf_size;
 }
 
+// A tree that came back from the GPU is checked before anything traverses it: every primitive in exactly one leaf,
+// every leaf's box around its primitives, every inner box around its children, ranges that tile the parent's.
+void check_device_tree(const std::vector<float>& bounds, const std::vector<int32_t>& ids, const Bvh& t) {
+    auto bad = [](const char* what) { throw std::runtime_error(std::string("device BVH build: invalid tree: ") + what); };
+    const size_t n = ids.size();
+    if (t.order.size() != n) bad("order length");
+    if (n == 0) return;
+    if (t.nodes.empty() || t.nodes.size() > 2 * n) bad("node count");
+    std::vector<int32_t> prim_of(n);  // slot -> primitive index, through the surface ids
+    {
+        int32_t max_id = 0;
+        for (int32_t id : ids) max_id = std::max(max_id, id);
+        std::vector<int32_t> prim_of_id((size_t)max_id + 1, -1);
+        for (size_t i = 0; i < n; ++i) prim_of_id[(size_t)ids[i]] = (int32_t)i;
+        for (size_t slot = 0; slot < n; ++slot) {
+            const int32_t id = t.order[slot];
+            if (id < 0 || id > max_id || prim_of_id[(size_t)id] < 0) bad("order is not a permutation");
+            prim_of[slot] = prim_of_id[(size_t)id], prim_of_id[(size_t)id] = -1;  // a second use fails
+        }
+    }
+    if (t.nodes[0].first != 0 || (size_t)t.nodes[0].count != n) bad("root range");
+    std::vector<uint8_t> visited(t.nodes.size(), 0);
+    std::vector<int32_t> stack{0};
+    size_t leaves = 0, covered = 0;
+    while (!stack.empty()) {
+        const int32_t i = stack.back();
+        stack.pop_back();
+        if (i < 0 || (size_t)i >= t.nodes.size() || visited[(size_t)i]) bad("child index");
+        visited[(size_t)i] = 1;
+        const BvhNode& nd = t.nodes[(size_t)i];
+        if (nd.count <= 0 || nd.first < 0 || (size_t)nd.first + (size_t)nd.count > n) bad("node range");
+        if (nd.is_leaf()) {
+            ++leaves, covered += (size_t)nd.count;
+            for (int32_t k = nd.first; k < nd.first + nd.count; ++k) {
+                const float* b = &bounds[6 * (size_t)prim_of[(size_t)k]];
+                if (!(nd.box.lo.x <= b[0] && nd.box.lo.y <= b[1] && nd.box.lo.z <= b[2] && nd.box.hi.x >= b[3] &&
+                      nd.box.hi.y >= b[4] && nd.box.hi.z >= b[5]))
+                    bad("leaf box");
+            }
+            continue;
+        }
+        if (nd.left < 0 || nd.right < 0 || (size_t)nd.left >= t.nodes.size() || (size_t)nd.right >= t.nodes.size()) bad("child index");
+        const BvhNode &l = t.nodes[(size_t)nd.left], &r = t.nodes[(size_t)nd.right];
+        if (l.first != nd.first || r.first != l.first + l.count || l.count + r.count != nd.count) bad("children do not tile the parent's range");
+        for (const BvhNode* c : {&l, &r})
+            if (!(nd.box.lo.x <= c->box.lo.x && nd.box.lo.y <= c->box.lo.y && nd.box.lo.z <= c->box.lo.z &&
+                  nd.box.hi.x >= c->box.hi.x && nd.box.hi.y >= c->box.hi.y && nd.box.hi.z >= c->box.hi.z))
+                bad("inner box");
+        stack.push_back(nd.right), stack.push_back(nd.left);
+    }
+    if (covered != n || leaves != t.n_leaves) bad("leaves do not cover the primitives");
+}
+
 constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured: 2 beats 4 and 8 by 4-5 %)
 
 // The tree the render kernels traverse: triangles, plus spheres/quads when the scene has too many of them to
 // test "loose".  Independent of the reference-topology tree, so the two builds run side by side.
-void build_render_tree(const rt_scene_desc& d, rt_scene& s) {
+void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
     const bool loose_ok = d.n_spheres + d.n_quads <= kMaxLoose;
     std::vector<int32_t>& tree_ids = s.render_ids;
     tree_ids.clear();
@@ -282,8 +335,26 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s) {
         if (d.surfaces[i].type == RT_SURF_TRIANGLE || !loose_ok) tree_ids.push_back((int32_t)i);
     }
     Bvh& rb = s.render_bvh;
-    if (d.use_bvh) {
-        build_render_bvh(d, tree_ids, getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : kRenderLeaf, rb);
+    const uint32_t max_leaf = getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : kRenderLeaf;
+    if (d.use_bvh && build_device >= 0) {
+        // opt-in (use_bvh == 2 or RT_BUILD=device): the same builder as build_render_bvh, level by level on the GPU.
+        // Its input is each primitive's f32 box, rounded outward from the bounds the host builder uses.
+        std::vector<float> bounds(6 * tree_ids.size());
+        for (size_t i = 0; i < tree_ids.size(); ++i) {
+            const rt_surface_ref& ref = d.surfaces[tree_ids[i]];
+            const Aabb b = true_bounds(d, ref).pad(ref.type == RT_SURF_QUAD ? 0.0001 : 0.0);
+            for (int a = 0; a < 3; ++a) {
+                float lo = (float)b.lo.get(a), hi = (float)b.hi.get(a);
+                if ((double)lo > b.lo.get(a)) lo = std::nextafterf(lo, -INFINITY);
+                if ((double)hi < b.hi.get(a)) hi = std::nextafterf(hi, INFINITY);
+                bounds[6 * i + a] = lo, bounds[6 * i + 3 + a] = hi;
+            }
+        }
+        if (hipSetDevice(build_device) != hipSuccess) throw std::runtime_error("device BVH build: cannot select the device");
+        build_render_bvh_device(bounds, tree_ids, max_leaf, rb);
+        check_device_tree(bounds, tree_ids, rb);
+    } else if (d.use_bvh) {
+        build_render_bvh(d, tree_ids, max_leaf, rb);
     } else {  // --no-bvh: one leaf, every surface tested by every ray (main.rs:60-65)
         rb = Bvh{};
         rb.order = tree_ids;
@@ -592,6 +663,7 @@ int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_sc
     try {
         auto hs = std::make_unique<HostScene>();
         load_scene_file(yaml_path, aspect_ratio, use_bvh != 0, *hs);
+        if (use_bvh == 2) hs->desc.use_bvh = 2;
         *out = &hs.release()->desc;
         return 0;
     } catch (const std::exception& e) {
@@ -604,6 +676,7 @@ int rt_example_scene(const char* name, double aspect_ratio, uint64_t seed, int u
     try {
         auto hs = std::make_unique<HostScene>();
         example_scene(name, aspect_ratio, seed, use_bvh != 0, *hs);
+        if (use_bvh == 2) hs->desc.use_bvh = 2;
         *out = &hs.release()->desc;
         return 0;
     } catch (const std::exception& e) {
@@ -628,7 +701,18 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
                 if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
             });
         {
-            auto render_job = std::async(std::launch::async, [&]() { build_render_tree(*desc, *s); });
+            const char* how = getenv("RT_BUILD");
+            int build_device = -1;  // -1: the render tree is built on the host
+            if ((desc->use_bvh == 2 || (desc->use_bvh && how && std::string(how) == "device")) && device != RT_DEVICE_NONE) {
+                if (device >= 0) build_device = device;
+                else HIP_CHECK(hipGetDevice(&build_device));
+            }
+            s->info.device_build = build_device >= 0 ? 1u : 0u;
+            auto render_job = std::async(std::launch::async, [&, build_device]() {
+                const auto r0 = std::chrono::steady_clock::now();
+                build_render_tree(*desc, *s, build_device);
+                s->info.render_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
+            });
             build_bvh(*desc, s->bvh);
             render_job.get();
         }

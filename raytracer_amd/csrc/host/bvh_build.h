@@ -44,5 +44,8 @@ namespace rt {
 // equal-t tie ranks need the reference's).  Binned SAH (32 bins, all three axes), scale-invariant cost,
 // leaves of at most `max_leaf` surfaces, built over the surface ids in `ids`.  `order` holds surface ids.
 void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out);
+// The same builder on the GPU (hip/bvh_device.hip), on the current device.  bounds6: lo.xyz hi.xyz per primitive,
+// f32, rounded outward; ids[i]: the surface id of primitive i.  Throws on a HIP error.
+void build_render_bvh_device(const std::vector<float>& bounds6, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out);
 
 }  // namespace rt

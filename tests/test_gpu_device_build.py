@@ -1,0 +1,93 @@
+"""The render tree built on the GPU (use_bvh = 2 / RT_BUILD=device; SURVEY §8 f2, hip/bvh_device.hip) against the
+host-built one.  Any valid tree over the same primitives finds the same closest hits (the leaf tests do not depend
+on the tree, boxes only cull, equal-t ties go by the reference's rank), so the f32 primary hits must be identical
+and the images equal up to summation order; the library itself refuses a device-built tree that is not a tree over
+exactly the scene's primitives (check_device_tree in api.cpp).  Needs an MI355X:  pytest -m gpu."""
+import numpy as np
+import pytest
+
+import synth
+from conftest import scene_path
+from test_gpu_parity import _same_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(ra, path, aspect):
+    host = ra.Scene(ra.load_scene(path, aspect), 0)
+    dev = ra.Scene(ra.load_scene(path, aspect, use_bvh="device"), 0)
+    hi, di = host.info(), dev.info()
+    assert hi.device_build == 0 and di.device_build == 1
+    assert di.n_surfaces == hi.n_surfaces and di.n_loose == hi.n_loose
+    # the reference-topology tree (tie ranks, parity kernel) is the host's in both
+    assert (di.n_nodes, di.n_leaves, di.max_depth) == (hi.n_nodes, hi.n_leaves, hi.max_depth)
+    assert np.array_equal(host.leaf_order(), dev.leaf_order())
+    return host, dev
+
+
+@pytest.mark.parametrize("name", ["teapot", "lucy", "cornell_lucy", "dual", "quads"])
+def test_device_built_tree_finds_the_same_hits(ra, name):
+    w, h = 480, 270
+    host, dev = _pair(ra, scene_path(name), w / h)
+    hi, di = host.info(), dev.info()
+    print(f"\n{name}: render tree host {hi.render_nodes} nodes depth {hi.render_depth} in {hi.render_build_ms:.1f} ms; "
+          f"device {di.render_nodes} nodes depth {di.render_depth} in {di.render_build_ms:.1f} ms")
+    assert di.render_max_leaf <= max(2, hi.render_max_leaf) and di.render_depth <= 56
+    # leaves of at most two primitives: a tree over n primitives has between n/2 and n leaves
+    assert hi.render_nodes / 2 <= di.render_nodes <= 2 * hi.render_nodes + 2
+    ids_h, t_h = host.primary_hits(w, h, precision=32)
+    ids_d, t_d = dev.primary_hits(w, h, precision=32)
+    assert np.array_equal(ids_h, ids_d) and np.array_equal(t_h, t_d)
+    # the f64 parity kernel walks the reference-topology tree: untouched
+    a, b = host.primary_hits(w, h, precision=64), dev.primary_hits(w, h, precision=64)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for kernel in (0, 1, 2):
+        img_h, st_h = host.render(240, 135, 4, kernel=kernel, collect_stats=True)
+        img_d, st_d = dev.render(240, 135, 4, kernel=kernel, collect_stats=True)
+        assert st_h.samples == st_d.samples
+        assert _same_image(img_h, img_d, 16), (name, kernel)
+    host.close(), dev.close()
+
+
+def test_device_build_of_synthetic_scenes(ra, tmp_path):
+    """Spheres and quads inside the tree, a degenerate deep tree, a scene small enough for one thread to finish."""
+    cases = [synth.many_prims(tmp_path), synth.deep_tree(tmp_path, 200), synth.deep_tree(tmp_path, 40, name="small")]
+    for path in cases:
+        w, h = 160, 120
+        host, dev = _pair(ra, path, w / h)
+        ids_h, t_h = host.primary_hits(w, h, precision=32)
+        ids_d, t_d = dev.primary_hits(w, h, precision=32)
+        assert np.array_equal(ids_h, ids_d) and np.array_equal(t_h, t_d), path
+        img_h, _ = host.render(w, h, 3)
+        img_d, _ = dev.render(w, h, 3)
+        assert _same_image(img_h, img_d, 9), path
+        host.close(), dev.close()
+
+
+def test_env_switch_and_no_bvh(ra, monkeypatch):
+    monkeypatch.setenv("RT_BUILD", "device")
+    s = ra.Scene(ra.load_scene(scene_path("teapot"), 1.5), 0)
+    assert s.info().device_build == 1
+    s.close()
+    # --no-bvh keeps its single leaf whatever the switch says
+    s = ra.Scene(ra.load_scene(scene_path("quads"), 1.5, use_bvh=False), 0)
+    assert s.info().render_nodes <= 1 or s.info().render_depth == 1
+    s.close()
+
+
+def test_cli_device_build_writes_the_same_image(tmp_path):
+    import subprocess
+
+    from PIL import Image
+
+    from conftest import ROOT
+
+    cli = f"{ROOT}/raytracer_amd/raytracer"
+    args = [cli, "--scene", scene_path("teapot"), "--width", "160", "--height", "90", "-n", "16", "--seed", "5", "--no-progress"]
+    a, b = tmp_path / "host.png", tmp_path / "device.png"
+    for out, extra in ((a, []), (b, ["--device-build"])):
+        r = subprocess.run(args + extra + ["-o", str(out)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    pa = np.asarray(Image.open(a).convert("RGB"), dtype=np.int32)
+    pb = np.asarray(Image.open(b).convert("RGB"), dtype=np.int32)
+    assert np.abs(pa - pb).max() <= 1 and (pa != pb).mean() <= 0.01
