@@ -432,7 +432,10 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
             const double qlo = std::floor((b.lo.get(a) - inflate - glo[a]) / gstep[a]) - 1.0;
             const double qhi = std::ceil((b.hi.get(a) + inflate - glo[a]) / gstep[a]) + 1.0;
             const uint32_t lo = (uint32_t)std::fmin(std::fmax(qlo, 0.0), 65535.0), hi = (uint32_t)std::fmin(std::fmax(qhi, 0.0), 65535.0);
-            w[a] = lo | (hi << 16);
+            // stored as centre and half-extent (child_slab: one fma to the centre plane, one each to the faces; no
+            // per-axis min/max): centre = floor of the mid-plane, half-extent = what still covers both faces
+            const uint32_t centre = (lo + hi) >> 1, half = std::max(centre - lo, hi - centre);
+            w[a] = centre | (half << 16);
         }
         s.nodes[2 * node + c] = uint4{w[0], w[1], w[2], (uint32_t)ref};
     };
@@ -441,7 +444,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         // synthetic root: child 0 = the leaf; child 1 = the grid's far corner over one dummy slot that can never
         // be hit
         put_child(0, 0, rb.nodes[0].box, ~0);
-        s.nodes[1] = uint4{0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)~(int32_t)n_tree};
+        s.nodes[1] = uint4{0x0000ffffu, 0x0000ffffu, 0x0000ffffu, (uint32_t)~(int32_t)n_tree};  // centre 65535, half-extent 0
     } else if (s.has_tree) {
         for (size_t i = 0; i < rb.nodes.size(); ++i) {
             const BvhNode& n = rb.nodes[i];

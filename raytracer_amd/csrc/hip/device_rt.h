@@ -383,12 +383,18 @@ __device__ __forceinline__ int stack_pop(int* stack, int stride, int& sp) {
 
 // One inner node: test both children's boxes against [tmin, best_t], go to the nearer hit child, defer the
 // other.  Returns the next node (>= 0 inner, < 0 leaf ~first_slot, kTraversalDone).
+// A child's box: per axis one word, centre | half-extent << 16 in grid units.  One fma reaches the centre plane, one
+// each the two faces (m -/+ e*|a|: whichever the ray's direction, the minus side is the near one), so no per-axis
+// min/max is needed — those issue at half the fma's rate (profiles/r1_valu_issue_rates.txt).
 __device__ __forceinline__ void child_slab(const uint4 c, const SlabRay& r, float tmin, float tmax_pad, float& tn, float& tf) {
-    const float ax = fmaf((float)(c.x & 0xffffu), r.ax, r.bx), bx = fmaf((float)(c.x >> 16), r.ax, r.bx);
-    const float ay = fmaf((float)(c.y & 0xffffu), r.ay, r.by), by = fmaf((float)(c.y >> 16), r.ay, r.by);
-    const float az = fmaf((float)(c.z & 0xffffu), r.az, r.bz), bz = fmaf((float)(c.z >> 16), r.az, r.bz);
-    tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_pad));
+    const float mx = fmaf((float)(c.x & 0xffffu), r.ax, r.bx), ex = (float)(c.x >> 16);
+    const float my = fmaf((float)(c.y & 0xffffu), r.ay, r.by), ey = (float)(c.y >> 16);
+    const float mz = fmaf((float)(c.z & 0xffffu), r.az, r.bz), ez = (float)(c.z >> 16);
+    const float nx = fmaf(-ex, fabsf(r.ax), mx), fx = fmaf(ex, fabsf(r.ax), mx);
+    const float ny = fmaf(-ey, fabsf(r.ay), my), fy = fmaf(ey, fabsf(r.ay), my);
+    const float nz = fmaf(-ez, fabsf(r.az), mz), fz = fmaf(ez, fabsf(r.az), mz);
+    tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+    tf = fminf(fminf(fx, fy), fminf(fz, tmax_pad));
 }
 template <bool STATS>
 __device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, float tmin, float best_t, int node,
