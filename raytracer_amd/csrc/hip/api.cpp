@@ -371,6 +371,20 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
     }
 }
 
+// An integer 0..32768 as IEEE binary16 bits, rounded up to the next representable value (11 significant bits):
+// the half-extent of a child box, which the kernels feed to v_fma_mix_f32 without a conversion instruction.
+uint32_t half_bits_up(uint32_t e) {
+    if (e == 0) return 0;
+    int top = 31 - __builtin_clz(e);  // e = 1.m * 2^top
+    if (top > 10) {
+        const int drop = top - 10;
+        e = ((e + (1u << drop) - 1u) >> drop) << drop;
+        top = 31 - __builtin_clz(e);  // the round-up may have carried into the next power of two
+    }
+    const uint32_t mant = top > 10 ? (e >> (top - 10)) & 0x3ffu : (e << (10 - top)) & 0x3ffu;
+    return ((uint32_t)(top + 15) << 10) | mant;
+}
+
 // Render tree + loose list -> f32 arrays of the render kernels.
 void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     const size_t n_surf = d.n_surfaces;
@@ -435,7 +449,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
             // stored as centre and half-extent (child_slab: one fma to the centre plane, one each to the faces; no
             // per-axis min/max): centre = floor of the mid-plane, half-extent = what still covers both faces
             const uint32_t centre = (lo + hi) >> 1, half = std::max(centre - lo, hi - centre);
-            w[a] = centre | (half << 16);
+            w[a] = centre | (half_bits_up(half) << 16);
         }
         s.nodes[2 * node + c] = uint4{w[0], w[1], w[2], (uint32_t)ref};
     };
@@ -444,7 +458,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         // synthetic root: child 0 = the leaf; child 1 = the grid's far corner over one dummy slot that can never
         // be hit
         put_child(0, 0, rb.nodes[0].box, ~0);
-        s.nodes[1] = uint4{0x0000ffffu, 0x0000ffffu, 0x0000ffffu, (uint32_t)~(int32_t)n_tree};  // centre 65535, half-extent 0
+        s.nodes[1] = uint4{0x0000ffffu, 0x0000ffffu, 0x0000ffffu, (uint32_t)~(int32_t)n_tree};  // centre 65535, half-extent +0.0
     } else if (s.has_tree) {
         for (size_t i = 0; i < rb.nodes.size(); ++i) {
             const BvhNode& n = rb.nodes[i];

@@ -383,13 +383,15 @@ __device__ __forceinline__ int stack_pop(int* stack, int stride, int& sp) {
 
 // One inner node: test both children's boxes against [tmin, best_t], go to the nearer hit child, defer the
 // other.  Returns the next node (>= 0 inner, < 0 leaf ~first_slot, kTraversalDone).
-// A child's box: per axis one word, centre | half-extent << 16 in grid units.  One fma reaches the centre plane, one
-// each the two faces (m -/+ e*|a|: whichever the ray's direction, the minus side is the near one), so no per-axis
-// min/max is needed — those issue at half the fma's rate (profiles/r1_valu_issue_rates.txt).
+// A child's box: per axis one word, centre (u16) | half-extent (binary16, rounded up) << 16, in grid units.  One fma
+// reaches the centre plane, one each the two faces (m -/+ e*|a|: whichever the ray's direction, the minus side is the
+// near one), so no per-axis min/max is needed — those issue at half the fma's rate
+// (profiles/r1_valu_issue_rates.txt) — and the half-extent enters v_fma_mix_f32 as it is, without a conversion.
 __device__ __forceinline__ void child_slab(const uint4 c, const SlabRay& r, float tmin, float tmax_pad, float& tn, float& tf) {
-    const float mx = fmaf((float)(c.x & 0xffffu), r.ax, r.bx), ex = (float)(c.x >> 16);
-    const float my = fmaf((float)(c.y & 0xffffu), r.ay, r.by), ey = (float)(c.y >> 16);
-    const float mz = fmaf((float)(c.z & 0xffffu), r.az, r.bz), ez = (float)(c.z >> 16);
+    typedef _Float16 Half2 __attribute__((ext_vector_type(2)));
+    const float mx = fmaf((float)(c.x & 0xffffu), r.ax, r.bx), ex = (float)__builtin_bit_cast(Half2, c.x).y;
+    const float my = fmaf((float)(c.y & 0xffffu), r.ay, r.by), ey = (float)__builtin_bit_cast(Half2, c.y).y;
+    const float mz = fmaf((float)(c.z & 0xffffu), r.az, r.bz), ez = (float)__builtin_bit_cast(Half2, c.z).y;
     const float nx = fmaf(-ex, fabsf(r.ax), mx), fx = fmaf(ex, fabsf(r.ax), mx);
     const float ny = fmaf(-ey, fabsf(r.ay), my), fy = fmaf(ey, fabsf(r.ay), my);
     const float nz = fmaf(-ez, fabsf(r.az), mz), fz = fmaf(ez, fabsf(r.az), mz);

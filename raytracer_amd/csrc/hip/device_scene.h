@@ -50,7 +50,7 @@ struct DevScene {
     // render tree (binned SAH, leaves <= 2): triangles, plus spheres/quads when a scene has too many of
     // them to test "loose"
     const uint4* nodes;         // 2 per inner node (32 B), one per child: {x, y, z, ref} with each axis word holding
-                                //   the child box's centre plane (low half) and half-extent (high half) on a 16-bit grid over
+                                //   the child box's centre plane (low half, u16) and half-extent (high half, binary16) on a 16-bit grid over
                                 //   the tree's bounds (rounded outward by at least a step), ref = child id: >= 0 inner
                                 //   node, < 0 leaf ~first_slot.  A node visit is two 16-byte fetches per lane
                                 //   instead of four: the kernels are bound by the vector L1's request rate.
