@@ -164,7 +164,7 @@ struct CameraSample {
     float time;
 };
 template <bool DIRECT>
-__device__ __forceinline__ CameraSample camera_sample(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
+__device__ __forceinline__ CameraSample camera_sample(const DevCamera& cam, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
                                                       uint32_t stratum, Rng& rng) {
     const uint32_t si = rp.sn_magic ? __umulhi(stratum, rp.sn_magic) : stratum / rp.sn, sj = stratum - si * rp.sn;
     float ju = -0.5f + rp.recip_sn * ((float)si + rng_u01(rng));
@@ -173,23 +173,46 @@ __device__ __forceinline__ CameraSample camera_sample(const DevScene& sc, const 
     float t = (float)(pj + 1) + jv;
     CameraSample cs;
     rng_in_unit_disk<DIRECT>(rng, cs.rx, cs.ry);  // always drawn, even for a pinhole (camera.rs:77)
-    cs.rx *= sc.cam.lens_radius, cs.ry *= sc.cam.lens_radius;
+    cs.rx *= cam.lens_radius, cs.ry *= cam.lens_radius;
     cs.time = rng_u01(rng);  // shutter time (camera.rs:80): without effect on stationary scenes
-    cs.d = f3(sc.cam.ll_rel) + s * f3(sc.cam.hor_px) + t * f3(sc.cam.ver_px);
+    cs.d = f3(cam.ll_rel) + s * f3(cam.hor_px) + t * f3(cam.ver_px);
     return cs;
 }
-__device__ __forceinline__ Ray camera_ray_of(const DevScene& sc, const CameraSample& cs) {
-    const F3 off = cs.rx * f3(sc.cam.u) + cs.ry * f3(sc.cam.v);
+__device__ __forceinline__ Ray camera_ray_of(const DevCamera& cam, const CameraSample& cs) {
+    const F3 off = cs.rx * f3(cam.u) + cs.ry * f3(cam.v);
     Ray ray;
-    ray.o = d3(sc.cam.origin) - d3(off);
+    ray.o = d3(cam.origin) - d3(off);
     ray.d = cs.d + off;
     ray.time = cs.time;
     return ray;
 }
+// Wave-uniform parameters that only rare code needs (the camera where samples are drawn, the hand-out plan where a
+// chunk is fetched) are read again from memory there, through the constant address space (scalar loads), instead of
+// living in SGPRs across every stage: the kernel holds more scalars than the 102 registers there are, and what
+// does not fit is parked in vector-register lanes and moved back with v_readlane on the hot path.  The address
+// passes through an empty asm so that the compiler cannot hoist the loads back to the kernel's entry.
+template <class T>
+__device__ __forceinline__ T reload_uniform(uintptr_t a) {
+    asm volatile("" : "+s"(a));
+    typedef const uint32_t __attribute__((address_space(4)))* UniformWords;
+    const UniformWords w = (UniformWords)a;
+    static_assert(sizeof(T) % 4 == 0, "copied word by word");
+    uint32_t words[sizeof(T) / 4];
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 4; ++i) words[i] = w[i];
+    T out;
+    __builtin_memcpy(&out, words, sizeof out);
+    return out;
+}
+// a by-value kernel argument, by its offset in the kernarg segment
+template <class T>
+__device__ __forceinline__ T reload_kernarg(size_t offset) {
+    return reload_uniform<T>((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
 template <bool DIRECT>
 __device__ __forceinline__ Ray camera_ray(const DevScene& sc, const DevRenderParams& rp, uint32_t pi, uint32_t pj,
                                           uint32_t stratum, Rng& rng) {
-    return camera_ray_of(sc, camera_sample<DIRECT>(sc, rp, pi, pj, stratum, rng));
+    return camera_ray_of(sc.cam, camera_sample<DIRECT>(sc.cam, rp, pi, pj, stratum, rng));
 }
 
 // ---------------------------------------------------------------- primitive tests
@@ -350,7 +373,10 @@ struct SlabRay {  // f32 ray in the form the fma slab test wants, in grid units:
                   // at t = q * a_[a] + b_[a], with a_ = grid_step / d and b_ = (grid_lo - o) / d
     float ax, ay, az, bx, by, bz;
 };
-__device__ __forceinline__ SlabRay slab_ray(const DevScene& sc, const Ray& ray) {
+struct DevGrid {  // DevScene::grid_lo, grid_step
+    float lo[3], step[3];
+};
+__device__ __forceinline__ SlabRay slab_ray(const DevGrid& grid, const Ray& ray) {
     SlabRay r;
     const F3 o = tof(ray.o), d = ray.d;
     // A zero direction component would make q*inf + (-o)*inf a NaN or a wrongly signed infinity in the fma slab
@@ -359,9 +385,13 @@ __device__ __forceinline__ SlabRay slab_ray(const DevScene& sc, const Ray& ray) 
     const float idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
     const float idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
     const float idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
-    r.ax = sc.grid_step[0] * idx, r.ay = sc.grid_step[1] * idy, r.az = sc.grid_step[2] * idz;
-    r.bx = (sc.grid_lo[0] - o.x) * idx, r.by = (sc.grid_lo[1] - o.y) * idy, r.bz = (sc.grid_lo[2] - o.z) * idz;
+    r.ax = grid.step[0] * idx, r.ay = grid.step[1] * idy, r.az = grid.step[2] * idz;
+    r.bx = (grid.lo[0] - o.x) * idx, r.by = (grid.lo[1] - o.y) * idy, r.bz = (grid.lo[2] - o.z) * idz;
     return r;
+}
+__device__ __forceinline__ SlabRay slab_ray(const DevScene& sc, const Ray& ray) {
+    static_assert(offsetof(DevScene, grid_step) == offsetof(DevScene, grid_lo) + 12, "DevGrid mirrors the two arrays");
+    return slab_ray(DevGrid{{sc.grid_lo[0], sc.grid_lo[1], sc.grid_lo[2]}, {sc.grid_step[0], sc.grid_step[1], sc.grid_step[2]}}, ray);
 }
 
 // Does the ray reach the render tree's bounds (grid planes 0 and 65535) at all within [tmin, best_t]?  Most

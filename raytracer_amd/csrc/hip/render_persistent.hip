@@ -22,7 +22,7 @@ namespace rt {
 
 constexpr int kBlock = 256;
 #ifndef RT_NODE_STEPS
-#define RT_NODE_STEPS 3
+#define RT_NODE_STEPS 4
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
@@ -49,6 +49,15 @@ struct PersistentPlan {
     // each — direction (3), generator state (2), and where the scene needs them lens sample (2) and shutter time (1).
     uint32_t stack_levels;
     uint32_t gen_words;
+};
+// the kernel's arguments as the kernarg segment lays them out (reload_kernarg)
+struct PersistentArgs {
+    DevScene sc;
+    DevRenderParams rp;
+    PersistentPlan plan;
+    float* acc;
+    DevCounters* counters;
+    uint32_t* work_counter;
 };
 constexpr uint32_t kGenLens = 5, kGenTime = 7;  // first word of the lens sample / of the shutter time in a batch
 
@@ -91,7 +100,6 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
     uint32_t acc_tile = 0xffffffffu;  // wave-uniform
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t seed = ((uint64_t)rp.seed_hi << 32) | rp.seed_lo;
 
     // wave-uniform cursor over the current chunk
     uint32_t chunk_tile = 0, chunk_first = 0, next_j = 0, chunk_total = 0;  // chunk_first: its first stratum
@@ -157,6 +165,11 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
             if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
             if (STATS && exhausted) drain_trips[2]++, drain_lanes[2] += n_shade;
             const bool mine = node == kStageShade;
+            // The scene's parameters as this stage sees them: read again from the kernel's arguments (scalar loads of
+            // the members used below) rather than kept in SGPRs across the node and leaf stages — see reload_uniform.
+            const DevScene ss = reload_kernarg<DevScene>(offsetof(PersistentArgs, sc));
+            const uint32_t max_depth = reload_kernarg<uint32_t>(offsetof(PersistentArgs, rp) + offsetof(DevRenderParams, max_depth));
+            float* const acc_now = reload_kernarg<float*>(offsetof(PersistentArgs, acc));
             unsigned long long t_part = 0;
             if (STATS) t_part = __builtin_readcyclecounter();
             // ---- shade the finished segment (scene/mod.rs:104-123)
@@ -167,30 +180,30 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
                     // hit did not scatter (see shade_bounce)
                     const Closest surface = best;
                     MediaSpans spans;
-                    media_spans(sc, ray, spans);
+                    media_spans(ss, ray, spans);
                     bool again, light = false;
                     F3 emitted = {0.f, 0.f, 0.f};
                     do {
                         again = false;
                         best = surface;
                         // the same light again and again (Q1) until a medium scatters or the depth runs out
-                        if (light && media_light_attempts(sc, spans, surface, 0.001f, rng, depth, rp.max_depth)) {
+                        if (light && media_light_attempts(ss, spans, surface, 0.001f, rng, depth, max_depth)) {
                             lsum = lsum + thr * emitted;
                             alive = false;
                             break;
                         }
-                        media_sample(sc, ray, 0.001f, rng, best, spans);
-                        alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
-                                                          rp.max_depth, &again, &emitted);
+                        media_sample(ss, ray, 0.001f, rng, best, spans);
+                        alive = shade_bounce<DIRECT, EXT>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
+                                                          max_depth, &again, &emitted);
                         light = again && best.h.slot > kMediumSlot && (emitted.x != 0.f || emitted.y != 0.f || emitted.z != 0.f);
                     } while (again && alive);
                 } else {
-                    alive = shade_bounce<DIRECT, EXT>(sc, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
-                                                      rp.max_depth);
+                    alive = shade_bounce<DIRECT, EXT>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
+                                                      max_depth);
                 }
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
-                    float* a = acc + (size_t)(pix >> 6) * 192u + (pix & 63u);
+                    float* a = acc_now + (size_t)(pix >> 6) * 192u + (pix & 63u);
                     if ((pix >> 6) == acc_tile) {  // the wave's current tile: sum in LDS, flushed once per chunk
                         atomicAdd(wacc + (pix & 63u), lsum.x);
                         atomicAdd(wacc + 64 + (pix & 63u), lsum.y);
@@ -211,37 +224,50 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
             while (need != 0ull && !exhausted) {
                 if (next_j >= chunk_total) {
                     uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(work_counter, 1u);
+                    if (lane == 0) c = atomicAdd(reload_kernarg<uint32_t*>(offsetof(PersistentArgs, work_counter)), 1u);
                     c = __builtin_amdgcn_readfirstlane(c);
-                    if (c >= plan.n_chunks) {
+                    if (c >= reload_kernarg<uint32_t>(offsetof(PersistentArgs, plan) + offsetof(PersistentPlan, n_chunks))) {
                         exhausted = true;
                         if (STATS) t_exhausted = wall_clock64();
                         break;
                     }
                     // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
-                    const uint32_t group = c / plan.n_tiles;
-                    chunk_tile = c - group * plan.n_tiles;
-                    flush_tile(acc, wacc, acc_tile, lane);
+                    // (the plan's words one by one, by scalar loads at wave-uniform offsets: once per chunk)
+                    auto plan_word = [](size_t member, int i) {
+                        return reload_kernarg<uint32_t>(offsetof(PersistentArgs, plan) + member + 4u * (size_t)i);
+                    };
+                    const uint32_t n_tiles = plan_word(offsetof(PersistentPlan, n_tiles), 0);
+                    const uint32_t group = c / n_tiles;
+                    chunk_tile = c - group * n_tiles;
+                    flush_tile(acc_now, wacc, acc_tile, lane);
                     acc_tile = chunk_tile;
                     int p = 0;
-                    while (p < kPhases - 1 && group >= plan.phase_end[p]) ++p;
-                    chunk_first = plan.phase_first[p] + (group - (p ? plan.phase_end[p - 1] : 0u)) * plan.phase_strata[p];
-                    chunk_total = 64u * min(plan.phase_strata[p], plan.phase_first[p + 1] - chunk_first);
+                    uint32_t prev_end = 0;
+                    while (p < kPhases - 1) {
+                        const uint32_t end = plan_word(offsetof(PersistentPlan, phase_end), p);
+                        if (group < end) break;
+                        prev_end = end, ++p;
+                    }
+                    const uint32_t strata = plan_word(offsetof(PersistentPlan, phase_strata), p);
+                    chunk_first = plan_word(offsetof(PersistentPlan, phase_first), p) + (group - prev_end) * strata;
+                    chunk_total = 64u * min(strata, plan_word(offsetof(PersistentPlan, phase_first), p + 1) - chunk_first);
                     next_j = 0;
                     gen_j = 0xffffffffu;
                 }
                 if (gen_j != (next_j & ~63u)) {  // wave-uniform: draw the batch next_j starts
                     gen_j = next_j & ~63u;
-                    const uint32_t px = (chunk_tile % plan.tiles_x) * 8u + (lane & 7u);
-                    const uint32_t py = (chunk_tile / plan.tiles_x) * 8u + (lane >> 3);  // image row, 0 = top
-                    const uint32_t stratum = rp.stratum_begin + (chunk_first + (gen_j >> 6)) * rp.stratum_step;
+                    const DevRenderParams gp = reload_kernarg<DevRenderParams>(offsetof(PersistentArgs, rp));
+                    const uint32_t tiles_x = (gp.width + 7u) >> 3;
+                    const uint32_t px = (chunk_tile % tiles_x) * 8u + (lane & 7u);
+                    const uint32_t py = (chunk_tile / tiles_x) * 8u + (lane >> 3);  // image row, 0 = top
+                    const uint32_t stratum = gp.stratum_begin + (chunk_first + (gen_j >> 6)) * gp.stratum_step;
                     Rng g;
                     // the stream key is the reference's idx: pi = idx % W, pj = H - idx/W - 1
-                    rng_init(g, seed, py * rp.width + px, stratum);
-                    const CameraSample cs = camera_sample<DIRECT>(sc, rp, px, rp.height - py - 1u, stratum, g);
+                    rng_init(g, ((uint64_t)gp.seed_hi << 32) | gp.seed_lo, py * gp.width + px, stratum);
+                    const CameraSample cs = camera_sample<DIRECT>(ss.cam, gp, px, gp.height - py - 1u, stratum, g);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     // a pixel of the tile that lies outside the frame: NaN marks "no sample"
-                    wgen[lane] = (px < rp.width && py < rp.height) ? cs.d.x : __builtin_nanf("");
+                    wgen[lane] = (px < gp.width && py < gp.height) ? cs.d.x : __builtin_nanf("");
                     wgen[64 + lane] = cs.d.y, wgen[128 + lane] = cs.d.z;
                     wgen[192 + lane] = __uint_as_float((uint32_t)g.s), wgen[256 + lane] = __uint_as_float((uint32_t)(g.s >> 32));
                     if (has_lens) wgen[kGenLens * 64u + lane] = cs.rx, wgen[(kGenLens + 1u) * 64u + lane] = cs.ry;
@@ -262,7 +288,7 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
                         if (has_lens) cs.rx = wgen[kGenLens * 64u + in_tile], cs.ry = wgen[(kGenLens + 1u) * 64u + in_tile];
                         if (EXT) cs.time = wgen[kGenTime * 64u + in_tile];
                         pix = chunk_tile * 64u + in_tile;  // slot in the tile-planar accumulator
-                        ray = camera_ray_of(sc, cs);
+                        ray = camera_ray_of(ss.cam, cs);
                         thr = {1.f, 1.f, 1.f};
                         depth = 0;
                         alive = true;
@@ -281,12 +307,12 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
                 if (alive) {
                     if (STATS) n_segments++;
                     closest_reset(best);
-                    loose_hits<STATS, EXT>(uniform_recs(sc.loose_rec), sc.n_loose, ray, 0.001f, best, st);
-                    if (sc.has_tree) {
-                        sr = slab_ray(sc, ray);
+                    loose_hits<STATS, EXT>(uniform_recs(ss.loose_rec), ss.n_loose, ray, 0.001f, best, st);
+                    if (ss.has_tree) {
+                        sr = slab_ray(ss, ray);
                         sp = 0;
                         // rays that never reach the tree's bounds are complete already: stay in the shade stage
-                        node = hits_tree_bounds(sc, sr, 0.001f, best.h.t) ? 0 : kStageShade;
+                        node = hits_tree_bounds(ss, sr, 0.001f, best.h.t) ? 0 : kStageShade;
                     }
                 } else {
                     node = kStageIdle;
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) voi
         }
     }
 
-    flush_tile(acc, wacc, acc_tile, lane);
+    flush_tile(reload_kernarg<float*>(offsetof(PersistentArgs, acc)), wacc, acc_tile, lane);
 
     if (STATS) {
         atomicAdd(&counters->segments, (unsigned long long)n_segments);
