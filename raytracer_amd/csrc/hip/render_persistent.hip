@@ -24,6 +24,9 @@ constexpr int kBlock = 256;
 #ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 4
 #endif
+#ifndef RT_LEAN_WAVES
+#define RT_LEAN_WAVES 5  // waves per SIMD the lean single-kind builds are compiled for (96 VGPRs)
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
@@ -83,7 +86,7 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
 }
 
 template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE>
-__global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? 5 : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+__global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
