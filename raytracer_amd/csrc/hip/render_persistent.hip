@@ -20,7 +20,10 @@
 
 namespace rt {
 
-constexpr int kBlock = 256;
+#ifndef RT_BLOCK
+#define RT_BLOCK 256
+#endif
+constexpr int kBlock = RT_BLOCK;
 #ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 4
 #endif
@@ -445,7 +448,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     if (plan.n_chunks == 0) return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);
     // Enough blocks to fill every CU at the occupancy the kernel's registers and LDS allow; surplus blocks are
     // harmless (they start when a slot frees up and find the counter exhausted).
-    const uint32_t blocks = std::min<uint32_t>(n_cus * 8u, (plan.n_chunks + 3u) / 4u);
+    const uint32_t blocks = std::min<uint32_t>(n_cus * 8u * (256u / kBlock), (plan.n_chunks + 3u) / 4u * (256u / kBlock));
     // near-first traversal keeps at most (depth - 1) deferred children
     // (LDS per block at ~1 KB per level: up to 27 levels -> 5 blocks per CU, 35 -> 4, 48 -> 3, 56 -> 2)
     if (tree_depth > 56) return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
