@@ -49,8 +49,9 @@ class FramePipeline:
     `render(buffer, k)` and `finish(buffer, k)` get the buffer's index (= its stream's).  With one rank there is
     nothing to overlap: a frame is finished in its own step."""
 
-    def __init__(self, buffers, world: int, render, finish, streams=None):
+    def __init__(self, buffers, world: int, render, finish, streams=None, reduce=None):
         self.buffers, self.world, self.render, self.finish, self.streams = buffers, world, render, finish, streams
+        self.reduce = reduce  # stand-in for the asynchronous sum-reduce (the one-GPU rehearsal's host reduce)
         self.work = [None] * len(buffers)
         self.open = [False] * len(buffers)
         self.i = 0
@@ -84,7 +85,10 @@ class FramePipeline:
                 import torch.distributed as dist
 
                 # RCCL's stream first waits for what buffer k's stream holds so far: this frame's render
-                self.work[k] = dist.reduce(self.buffers[k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+                if self.reduce is not None:
+                    self.work[k] = self.reduce(self.buffers[k], k)
+                else:
+                    self.work[k] = dist.reduce(self.buffers[k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
         if self.world > 1:
             self._finish((k - 1) % len(self.buffers))  # the frame before: its reduce ran beside this render
         else:
@@ -232,6 +236,10 @@ def main() -> None:
 
     import raytracer_amd as ra
 
+    if os.environ.get("RT_BENCH_HANG_DUMP"):  # debugging aid: where is every thread after N seconds? (then exit)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_HANG_DUMP"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,12 +247,21 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # Rehearsal of the several-rank flow on a one-GPU box (RT_BENCH_REHEARSE_ONE_GPU=1): every rank on GPU 0, the
+    # collectives over gloo instead of RCCL (which refuses two ranks on one device).  The figures mean nothing — the
+    # ranks share the card — and the line says so; what it exercises is the pipeline, the streams and the timing code.
+    rehearsal = world > 1 and os.environ.get("RT_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     scene_file = os.path.join(ROOT, "scenes", f"{args.scene}.yaml")
     w, h = args.width, args.height
@@ -300,7 +317,22 @@ def main() -> None:
 
     # a step = render this rank's strata slice of one frame + the frame's sum-reduce + tonemap on rank 0; with
     # several ranks the reduce of one frame and the drain of its render overlap the render of the next
-    frames = FramePipeline(fbs, world, render, tonemap, streams)
+    def host_reduce(buf, k):
+        # rehearsal only: gloo's reduce of device tensors hangs on this image when GPU work is in flight (with any
+        # kernels, not just these), so the ranks' frames are summed over host copies, awaited at once
+        streams[k].synchronize()
+        host = buf.cpu()
+        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            buf.copy_(host)
+        return None
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    frames = FramePipeline(fbs, world, render, tonemap, streams, host_reduce if rehearsal else None)
     one_step = frames.step
 
     def fence():
@@ -325,9 +357,7 @@ def main() -> None:
         kernel_ms = [elapsed / args.steps * 1e3] * args.steps
         kernel_events.clear()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = max_over_ranks(elapsed)
 
     samples_per_step = w * h * sn * sn
     value = samples_per_step * args.steps / elapsed / 1e6
@@ -344,9 +374,7 @@ def main() -> None:
     fence()
     elapsed_other = time.perf_counter() - t1
     if world > 1:
-        tmax = torch.tensor([elapsed_other], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed_other = float(tmax.item())
+        elapsed_other = max_over_ranks(elapsed_other)
     sampler = main_sampler
     kernel_ms = kernel_ms[:args.steps]
     kernel_events.clear()
@@ -381,7 +409,8 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": f"the reference's own scene file scenes/{args.scene}.yaml + its OBJ mesh (not synthetic)",
             "config": {"workload": workload, "seconds_per_frame": round(elapsed / args.steps, 4),
-                       "parallelism": f"strata-sharded x{world}, 1 RCCL sum-reduce/frame" if world > 1 else "1 GPU",
+                       "parallelism": (f"REHEARSAL: {world} ranks sharing one GPU, gloo" if rehearsal else
+                                       f"strata-sharded x{world}, 1 RCCL sum-reduce/frame") if world > 1 else "1 GPU",
                        "scene_surfaces": int(info.n_surfaces), "render_bvh_nodes": int(info.render_nodes),
                        "render_bvh_depth": int(info.render_depth), "loose_prims": int(info.n_loose),
                        "scene_setup_s": round(setup_s, 3), "scene_load_s": round(load_s, 3),

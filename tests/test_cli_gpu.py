@@ -72,3 +72,35 @@ def test_group_reduce_sum_one_member_clique(ra):
     assert torch.equal(x, want)
     assert lib.rt_group_reduce_sum(g, bufs, x.numel(), 3, None) != 0  # a root outside the clique is refused
     lib.rt_group_destroy(g)
+
+
+def test_bench_two_rank_flow_rehearsed_on_one_gpu(tmp_path):
+    """bench.py's several-rank flow — strata slices, a stream per framebuffer, two renders in flight, the frame
+    pipeline, max-over-ranks timing, rank 0's line and image — with two ranks sharing this box's one GPU.  RCCL
+    refuses two ranks on one device, so the rehearsal sums over gloo through host copies (bench.py says so in the
+    line); the frame must equal the one-rank frame."""
+    import json
+    import socket
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    common = ["--scene", "teapot", "--width", "320", "--height", "180", "--spp", "64", "--steps", "3", "--warmup", "1",
+              "--no-cpu-baseline"]
+    one, two = tmp_path / "one.png", tmp_path / "two.png"
+    r = subprocess.run([sys.executable, f"{ROOT}/bench.py", "--gpus", "1", "--png", str(one)] + common,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(__import__("os").environ, RT_BENCH_REHEARSE_ONE_GPU="1", RT_BENCH_HANG_DUMP="200")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), f"{ROOT}/bench.py", "--gpus", "2", "--png", str(two)] + common,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and "REHEARSAL" in line["config"]["parallelism"]
+    assert "cpu_baseline" not in line and line["roofline"]["traffic"] is None
+    pa, pb = _png(one), _png(two)
+    assert pa.shape == pb.shape == (180, 320, 3)
+    assert np.abs(pa - pb).max() <= 1 and (pa != pb).mean() <= 0.01  # same sample set, summed in another order
