@@ -11,7 +11,7 @@ Bars (BASELINE.json north_star):
       flips      hit <-> miss, or |dt|/t > 1e-5: budgeted per scene at 2x the measured count (floor 4 pixels);
     t must be within 1e-5 relative wherever ids agree, except on a budgeted handful of grazing pixels (a ray
     direction rounded to f32 moves a silhouette-grazing root by more), and within 2e-4 everywhere.
-    Measured table: DESIGN.md §2 (tools/parity_table.py).
+    Measured table: DESIGN.md §2 (tests/parity_table.py).
   * images at equal spp: per-channel RMSE <= IMG_RMSE and mean luminance within IMG_LUM relative.  Oracle and
     GPU draw identical variates, so most paths coincide and the residual is the f32-vs-f64 path divergence:
     measured RMSE <= 0.0015 at 16 spp and <= 0.0007 at 1024 spp, luminance within 2.7e-4 (cornell_lucy, the worst).
