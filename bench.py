@@ -41,8 +41,8 @@ def reduce_framebuffer(fb, world: int) -> None:
 
 
 class FramePipeline:
-    """Two framebuffers in turn, each with a stream of its own when `streams` is given: frame i+1's render is
-    enqueued on the other stream while frame i's render drains (rt_render_device keeps two scratch sets per scene
+    """Framebuffers in turn, each with a stream of its own when `streams` is given: frame i+1's render is
+    enqueued on the next stream while frame i's render drains (rt_render_device keeps three scratch sets per scene
     for exactly this), frame i's sum-reduce runs on RCCL's stream beside frame i+1's render, and frame i is finished
     — reduce awaited on its stream, `finish(buffer, k)` called, e.g. the tonemap — after frame i+1's render was
     issued.  A buffer is rendered into again only after the frame it held was finished, in its stream's order.
@@ -282,7 +282,7 @@ def main() -> None:
     setup_s = time.perf_counter() - t0
     info = scene.info()
 
-    fbs = [torch.empty((h, w, 3), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    fbs = [torch.empty((h, w, 3), dtype=torch.float32, device=dev) for _ in range(3 if world > 1 else 1)]
     fb = fbs[0]
     rgb8 = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
     begin, step_ = strata_slice(rank, world)

@@ -227,9 +227,9 @@ typedef struct rt_stats {
  * (pj = height - idx/width - 1, main.rs:158), un-normalised radiance SUM over the strata of this
  * call (overwritten, not accumulated).  `stream` is a hipStream_t (NULL = default stream); the call
  * returns after enqueueing unless stats != NULL, in which case it synchronises the stream.
- * Scratch (tile accumulator, chunk cursor, counters, events) is kept with the scene in TWO sets used in turn, so
- * one host thread may keep two renders of one scene in flight on two streams (e.g. double-buffered frames); a
- * third call re-uses the first set and is ordered after that set's previous use by an event wait on its stream.
+ * Scratch (tile accumulator, chunk cursor, counters, events) is kept with the scene in THREE sets used in turn, so
+ * one host thread may keep up to three renders of one scene in flight on as many streams (frames in turn); a
+ * fourth call re-uses the first set and is ordered after that set's previous use by an event wait on its stream.
  * The persistent and pool organisations take the sets in turn; the wavefront one has one set of queues and
  * serialises.  Growing the accumulator for a larger frame (hipFree + hipMalloc) waits for the set's last use. */
 int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream,

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("scenes", nargs="+")
 ap.add_argument("--slice", type=int, default=8)
 ap.add_argument("--frames", type=int, default=12)
+ap.add_argument("--streams", type=int, default=2, help="renders kept in flight (the library holds that many scratch sets)")
 ap.add_argument("--tail", default="", help="comma list of RT_TAIL_K values to sweep (default: the library's own)")
 a = ap.parse_args()
 w, h, sn = 1920, 1080, 32
@@ -25,8 +26,8 @@ w, h, sn = 1920, 1080, 32
 def probe(s, name, tail):
     if tail is not None:
         os.environ["RT_TAIL_K"] = tail
-    fbs = [torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0") for _ in range(2)]
-    streams = [torch.cuda.Stream() for _ in range(2)]
+    fbs = [torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0") for _ in range(a.streams)]
+    streams = [torch.cuda.Stream() for _ in range(a.streams)]
     full = min(s.render_device(fbs[0].data_ptr(), w, h, sn).kernel_ms for _ in range(2))
     one = min(s.render_device(fbs[0].data_ptr(), w, h, sn, stratum_step=a.slice).kernel_ms for _ in range(3))
     torch.cuda.synchronize()
@@ -37,12 +38,12 @@ def probe(s, name, tail):
     serial = (time.perf_counter() - t0) / a.frames * 1e3
     t0 = time.perf_counter()
     for i in range(a.frames):
-        s.render_device(fbs[i % 2].data_ptr(), w, h, sn, stratum_step=a.slice, stream=streams[i % 2].cuda_stream,
+        s.render_device(fbs[i % a.streams].data_ptr(), w, h, sn, stratum_step=a.slice, stream=streams[i % a.streams].cuda_stream,
                         want_stats=False)
     torch.cuda.synchronize()
     overlapped = (time.perf_counter() - t0) / a.frames * 1e3
     print(f"{name} tail {tail}: full frame {full:.2f} ms; slice kernel {one:.2f} ms; per frame awaited {serial:.2f} ms, "
-          f"two streams {overlapped:.2f} ms", flush=True)
+          f"{a.streams} streams {overlapped:.2f} ms", flush=True)
 
 
 for name in a.scenes:
