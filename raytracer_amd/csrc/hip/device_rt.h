@@ -204,7 +204,8 @@ __device__ __forceinline__ T reload_uniform(uintptr_t a) {
     __builtin_memcpy(&out, words, sizeof out);
     return out;
 }
-// a by-value kernel argument, by its offset in the kernarg segment
+// a by-value kernel argument, by its offset in the kernarg segment.  KERNELS ONLY: in a called (noinline) function
+// the intrinsic lowers to a null pointer — pass the address down and use reload_uniform there.
 template <class T>
 __device__ __forceinline__ T reload_kernarg(size_t offset) {
     return reload_uniform<T>((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offset);

@@ -88,6 +88,35 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// One batch of camera samples — stratum `local_stratum` of this call's slice, for the 64 pixels of `tile`, lane l
+// drawing pixel l's — into the wave's LDS batch.  Out of line: it runs once per 64 samples, and inlined its
+// registers count against every stage of the kernel.
+template <bool DIRECT, bool EXT>
+__device__ __attribute__((noinline)) void draw_batch(const void* kernarg, float* wgen, uint32_t tile, uint32_t local_stratum,
+                                                    bool has_lens) {
+    // (the kernarg segment's address is the kernel's to know — in a called function the intrinsic yields null — and
+    // arrives in vector registers like every argument: made scalar again for the scalar loads)
+    const uintptr_t ka = uniform_address(kernarg);
+    const uint32_t lane = threadIdx.x & 63u;
+    const DevRenderParams gp = reload_uniform<DevRenderParams>(ka + offsetof(PersistentArgs, rp));
+    const DevCamera cam = reload_uniform<DevCamera>(ka + offsetof(PersistentArgs, sc) + offsetof(DevScene, cam));
+    const uint32_t tiles_x = (gp.width + 7u) >> 3;
+    const uint32_t px = (tile % tiles_x) * 8u + (lane & 7u);
+    const uint32_t py = (tile / tiles_x) * 8u + (lane >> 3);  // image row, 0 = top
+    const uint32_t stratum = gp.stratum_begin + local_stratum * gp.stratum_step;
+    Rng g;
+    // the stream key is the reference's idx: pi = idx % W, pj = H - idx/W - 1
+    rng_init(g, ((uint64_t)gp.seed_hi << 32) | gp.seed_lo, py * gp.width + px, stratum);
+    const CameraSample cs = camera_sample<DIRECT>(cam, gp, px, gp.height - py - 1u, stratum, g);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // a pixel of the tile that lies outside the frame: NaN marks "no sample"
+    wgen[lane] = (px < gp.width && py < gp.height) ? cs.d.x : __builtin_nanf("");
+    wgen[64 + lane] = cs.d.y, wgen[128 + lane] = cs.d.z;
+    wgen[192 + lane] = __uint_as_float((uint32_t)g.s), wgen[256 + lane] = __uint_as_float((uint32_t)(g.s >> 32));
+    if (has_lens) wgen[kGenLens * 64u + lane] = cs.rx, wgen[(kGenLens + 1u) * 64u + lane] = cs.ry;
+    if (EXT) wgen[kGenTime * 64u + lane] = cs.time;
+}
+
 template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE>
 __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
@@ -262,22 +291,8 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MI
                 }
                 if (gen_j != (next_j & ~63u)) {  // wave-uniform: draw the batch next_j starts
                     gen_j = next_j & ~63u;
-                    const DevRenderParams gp = reload_kernarg<DevRenderParams>(offsetof(PersistentArgs, rp));
-                    const uint32_t tiles_x = (gp.width + 7u) >> 3;
-                    const uint32_t px = (chunk_tile % tiles_x) * 8u + (lane & 7u);
-                    const uint32_t py = (chunk_tile / tiles_x) * 8u + (lane >> 3);  // image row, 0 = top
-                    const uint32_t stratum = gp.stratum_begin + (chunk_first + (gen_j >> 6)) * gp.stratum_step;
-                    Rng g;
-                    // the stream key is the reference's idx: pi = idx % W, pj = H - idx/W - 1
-                    rng_init(g, ((uint64_t)gp.seed_hi << 32) | gp.seed_lo, py * gp.width + px, stratum);
-                    const CameraSample cs = camera_sample<DIRECT>(ss.cam, gp, px, gp.height - py - 1u, stratum, g);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    // a pixel of the tile that lies outside the frame: NaN marks "no sample"
-                    wgen[lane] = (px < gp.width && py < gp.height) ? cs.d.x : __builtin_nanf("");
-                    wgen[64 + lane] = cs.d.y, wgen[128 + lane] = cs.d.z;
-                    wgen[192 + lane] = __uint_as_float((uint32_t)g.s), wgen[256 + lane] = __uint_as_float((uint32_t)(g.s >> 32));
-                    if (has_lens) wgen[kGenLens * 64u + lane] = cs.rx, wgen[(kGenLens + 1u) * 64u + lane] = cs.ry;
-                    if (EXT) wgen[kGenTime * 64u + lane] = cs.time;
+                    draw_batch<DIRECT, EXT>((const void*)__builtin_amdgcn_kernarg_segment_ptr(), wgen, chunk_tile,
+                                            chunk_first + (gen_j >> 6), has_lens);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
                 const uint32_t avail = gen_j + 64u - next_j;  // what is left of the batch (chunks are whole batches)
