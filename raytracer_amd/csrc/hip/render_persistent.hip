@@ -88,6 +88,42 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// The next chunk of the launch's hand-out: which tile, its first stratum (in this call's slice), how many samples
+// (0: no work left).  The wave's tile sums go to the accumulator on the way (the chunk's tile becomes the wave's
+// current one).  Out of line like draw_batch: once per chunk.
+struct ChunkOfWork {
+    uint32_t tile, first, total;
+};
+__device__ __attribute__((noinline)) ChunkOfWork next_chunk(const void* kernarg, float* wacc, uint32_t acc_tile) {
+    const uintptr_t ka = uniform_address(kernarg);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(reload_uniform<uint32_t*>(ka + offsetof(PersistentArgs, work_counter)), 1u);
+    c = __builtin_amdgcn_readfirstlane(c);
+    // (the plan's words one by one, by scalar loads at wave-uniform offsets)
+    auto plan_word = [ka](size_t member, int i) {
+        return reload_uniform<uint32_t>(ka + offsetof(PersistentArgs, plan) + member + 4u * (size_t)i);
+    };
+    if (c >= plan_word(offsetof(PersistentPlan, n_chunks), 0)) return ChunkOfWork{0u, 0u, 0u};
+    // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
+    const uint32_t n_tiles = plan_word(offsetof(PersistentPlan, n_tiles), 0);
+    const uint32_t group = c / n_tiles;
+    ChunkOfWork ch;
+    ch.tile = c - group * n_tiles;
+    flush_tile(reload_uniform<float*>(ka + offsetof(PersistentArgs, acc)), wacc, (uint32_t)__builtin_amdgcn_readfirstlane((int)acc_tile), lane);
+    int p = 0;
+    uint32_t prev_end = 0;
+    while (p < kPhases - 1) {
+        const uint32_t end = plan_word(offsetof(PersistentPlan, phase_end), p);
+        if (group < end) break;
+        prev_end = end, ++p;
+    }
+    const uint32_t strata = plan_word(offsetof(PersistentPlan, phase_strata), p);
+    ch.first = plan_word(offsetof(PersistentPlan, phase_first), p) + (group - prev_end) * strata;
+    ch.total = 64u * min(strata, plan_word(offsetof(PersistentPlan, phase_first), p + 1) - ch.first);
+    return ch;
+}
+
 // One batch of camera samples — stratum `local_stratum` of this call's slice, for the 64 pixels of `tile`, lane l
 // drawing pixel l's — into the wave's LDS batch.  Out of line: it runs once per 64 samples, and inlined its
 // registers count against every stage of the kernel.
@@ -258,34 +294,16 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MI
             unsigned long long need = __ballot(mine && !alive);
             while (need != 0ull && !exhausted) {
                 if (next_j >= chunk_total) {
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(reload_kernarg<uint32_t*>(offsetof(PersistentArgs, work_counter)), 1u);
-                    c = __builtin_amdgcn_readfirstlane(c);
-                    if (c >= reload_kernarg<uint32_t>(offsetof(PersistentArgs, plan) + offsetof(PersistentPlan, n_chunks))) {
+                    const ChunkOfWork ch = next_chunk((const void*)__builtin_amdgcn_kernarg_segment_ptr(), wacc, acc_tile);
+                    chunk_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.total);
+                    if (chunk_total == 0u) {
                         exhausted = true;
                         if (STATS) t_exhausted = wall_clock64();
                         break;
                     }
-                    // tile-minor order: concurrently running waves work on neighbouring tiles of one strata group
-                    // (the plan's words one by one, by scalar loads at wave-uniform offsets: once per chunk)
-                    auto plan_word = [](size_t member, int i) {
-                        return reload_kernarg<uint32_t>(offsetof(PersistentArgs, plan) + member + 4u * (size_t)i);
-                    };
-                    const uint32_t n_tiles = plan_word(offsetof(PersistentPlan, n_tiles), 0);
-                    const uint32_t group = c / n_tiles;
-                    chunk_tile = c - group * n_tiles;
-                    flush_tile(acc_now, wacc, acc_tile, lane);
+                    chunk_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.tile);
+                    chunk_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.first);
                     acc_tile = chunk_tile;
-                    int p = 0;
-                    uint32_t prev_end = 0;
-                    while (p < kPhases - 1) {
-                        const uint32_t end = plan_word(offsetof(PersistentPlan, phase_end), p);
-                        if (group < end) break;
-                        prev_end = end, ++p;
-                    }
-                    const uint32_t strata = plan_word(offsetof(PersistentPlan, phase_strata), p);
-                    chunk_first = plan_word(offsetof(PersistentPlan, phase_first), p) + (group - prev_end) * strata;
-                    chunk_total = 64u * min(strata, plan_word(offsetof(PersistentPlan, phase_first), p + 1) - chunk_first);
                     next_j = 0;
                     gen_j = 0xffffffffu;
                 }
