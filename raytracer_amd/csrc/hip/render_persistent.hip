@@ -449,7 +449,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
                                     uint32_t n_cus, float* d_acc, float* d_rgb_sum, DevCounters* counters,
                                     uint32_t* work_counter, bool stats, hipStream_t stream) {
     PersistentPlan plan;
-    plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T")) : 40;
+    plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T")) : 36;
     plan.node_bias = getenv("RT_NODE_BIAS") ? atoi(getenv("RT_NODE_BIAS")) : 2;
     plan.tiles_x = (rp.width + 7u) >> 3;
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
