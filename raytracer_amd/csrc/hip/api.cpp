@@ -2,6 +2,9 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -144,6 +147,31 @@ struct rt_scene {
 };
 
 namespace {
+
+// Debugging aid (RT_SEGV_TRACE=1): the faulting thread's stack on SIGSEGV / SIGBUS / SIGABRT, on an alternate stack
+// so that a stack overflow prints too.
+struct SegvTrace {
+    static void handler(int sig) {
+        void* frames[64];
+        const int n = backtrace(frames, 64);
+        const char msg[] = "librt_amd: fatal signal, stack of the faulting thread:\n";
+        (void)!write(2, msg, sizeof msg - 1);
+        backtrace_symbols_fd(frames, n, 2);
+        signal(sig, SIG_DFL);
+        raise(sig);
+    }
+    SegvTrace() {
+        if (!getenv("RT_SEGV_TRACE")) return;
+        static char alt[1 << 16];
+        stack_t ss{};
+        ss.ss_sp = alt, ss.ss_size = sizeof alt;
+        sigaltstack(&ss, nullptr);  // (this thread's; other threads fall back to their own stack)
+        struct sigaction sa{};
+        sa.sa_handler = handler;
+        sa.sa_flags = SA_ONSTACK;
+        for (int sig : {SIGSEGV, SIGBUS, SIGABRT}) sigaction(sig, &sa, nullptr);
+    }
+} g_segv_trace;
 
 template <typename T>
 const T* upload(rt_scene& s, const std::vector<T>& v) {
@@ -713,12 +741,10 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         validate(*desc);
         auto s = std::make_unique<rt_scene>();
         auto t0 = std::chrono::steady_clock::now();
-        // a cold process spends ~0.1-0.2 s creating the device context: do that beside the tree builds
-        std::future<void> warm_up;
-        if (device >= 0)
-            warm_up = std::async(std::launch::async, [device]() {
-                if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
-            });
+        // The device context (0.1-0.2 s in a cold process: HIP runtime, code objects) is NOT created beside the tree
+        // builds any more: with the runtime initialising on one thread while the builds' threads ran, one cold start in
+        // 50-100 ended in a segmentation fault inside scene creation (160 starts without the overlap: none); the
+        // 40 ms the overlap saved are not worth that.  The first HIP call below creates the context.
         {
             const char* how = getenv("RT_BUILD");
             int build_device = -1;  // -1: the render tree is built on the host
@@ -727,6 +753,12 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
                 else HIP_CHECK(hipGetDevice(&build_device));
             }
             s->info.device_build = build_device >= 0 ? 1u : 0u;
+            if (build_device >= 0) {
+                // the device build runs on a thread of its own beside the reference-topology build: the context is
+                // created here first, on this thread, before any other thread exists (see above)
+                DeviceGuard first_use(build_device);
+                HIP_CHECK(hipFree(nullptr));
+            }
             auto render_job = std::async(std::launch::async, [&, build_device]() {
                 const auto r0 = std::chrono::steady_clock::now();
                 build_render_tree(*desc, *s, build_device);
@@ -762,7 +794,6 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
             *out = s.release();
             return 0;
         }
-        if (warm_up.valid()) warm_up.get();
         if (device < 0) HIP_CHECK(hipGetDevice(&device));
         s->device = device;
         DeviceGuard guard(device);
