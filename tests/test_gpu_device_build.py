@@ -50,8 +50,10 @@ def test_device_built_tree_finds_the_same_hits(ra, name):
 
 
 def test_device_build_of_synthetic_scenes(ra, tmp_path):
-    """Spheres and quads inside the tree, a degenerate deep tree, a scene small enough for one thread to finish."""
-    cases = [synth.many_prims(tmp_path), synth.deep_tree(tmp_path, 200), synth.deep_tree(tmp_path, 40, name="small")]
+    """Spheres and quads inside the tree, a degenerate deep tree, scenes small enough for one thread to finish (fewer
+    primitives than the small-node threshold: no level pass runs at all), a single triangle."""
+    cases = [synth.many_prims(tmp_path), synth.deep_tree(tmp_path, 200), synth.deep_tree(tmp_path, 40, name="small"),
+             synth.deep_tree(tmp_path, 6, name="tiny"), synth.deep_tree(tmp_path, 1, name="one")]
     for path in cases:
         w, h = 160, 120
         host, dev = _pair(ra, path, w / h)
