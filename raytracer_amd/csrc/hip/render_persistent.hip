@@ -216,7 +216,8 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MI
         const int n_shade = __popcll(m_shade), n_leaf = __popcll(m_leaf), n_node = __popcll(m_node);
         if ((n_shade | n_leaf | n_node) == 0) break;  // every lane idle: no paths in flight, no work left
 
-        const bool run_shade = n_shade >= plan.shade_threshold || (n_node | n_leaf) == 0;
+        // TREE == 4: a scene without a render tree (every primitive loose) — no node or leaf stage is compiled in
+        const bool run_shade = TREE == 4 || n_shade >= plan.shade_threshold || (n_node | n_leaf) == 0;
         if (STATS) t_begin = __builtin_readcyclecounter();
         if (!run_shade && n_node * plan.node_bias >= n_leaf * 4) {
             if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MI
                     if (STATS) n_segments++;
                     closest_reset(best);
                     loose_hits<STATS, EXT>(uniform_recs(ss.loose_rec), ss.n_loose, ray, 0.001f, best, st);
-                    if (ss.has_tree) {
+                    if (TREE != 4 && ss.has_tree) {
                         sr = slab_ray(ss, ray);
                         sp = 0;
                         // rays that never reach the tree's bounds are complete already: stay in the shade stage
@@ -426,8 +427,10 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
     hipLaunchKernelGGL((render_persistent_kernel<STATS, DIRECT, EXT_, MEDIA_, TREE_>), dim3(blocks), dim3(kBlock), lds, \
                        stream, sc, rp, plan, d_acc, counters, work_counter)
     if (sc.ext && sc.n_media) RT_LAUNCH(true, true, 0);
+    else if (sc.ext && !sc.has_tree) RT_LAUNCH(true, false, 4);
     else if (sc.ext && sc.tree_kind == 2u) RT_LAUNCH(true, false, 2);
     else if (sc.ext) RT_LAUNCH(true, false, 0);
+    else if (!sc.has_tree) RT_LAUNCH(false, false, 4);
     else if (sc.tree_kind == 1u) RT_LAUNCH(false, false, 1);
     else if (sc.tree_kind == 2u) RT_LAUNCH(false, false, 2);
     else if (sc.tree_kind == 3u) RT_LAUNCH(false, false, 3);
