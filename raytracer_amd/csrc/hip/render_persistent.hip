@@ -30,6 +30,9 @@ constexpr int kBlock = RT_BLOCK;
 #ifndef RT_LEAN_WAVES
 #define RT_LEAN_WAVES 5  // waves per SIMD the lean single-kind builds are compiled for (96 VGPRs)
 #endif
+#ifndef RT_NOTREE_WAVES
+#define RT_NOTREE_WAVES 8  // the build without a render tree: 64 VGPRs with 16 dwords spilled (76 unforced, six waves: quads -7 %, distant -3 %)
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
@@ -154,7 +157,7 @@ __device__ __attribute__((noinline)) void draw_batch(const void* kernarg, float*
 }
 
 template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE>
-__global__ __launch_bounds__(kBlock, (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+__global__ __launch_bounds__(kBlock, (TREE == 4 && !EXT) ? RT_NOTREE_WAVES : (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
