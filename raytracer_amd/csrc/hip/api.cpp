@@ -123,6 +123,7 @@ struct rt_scene {
     std::vector<uint8_t> image_rgb;
     std::vector<uint4> image_dims;
     bool ext = false;  // any texture or moving sphere
+    bool noise = false;  // a Perlin-noise texture among them (the kernels' NOISE builds)
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
     std::vector<Node64> nodes64;
@@ -540,7 +541,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     s.spheres.assign(4 * (d.n_spheres + 1), 0.0);  // + the never-hit dummy
     s.spheres[4 * d.n_spheres + 3] = std::nan("");
     s.sphere_end.assign(3 * (d.n_spheres + 1), 0.0);
-    s.ext = false;
+    s.ext = false, s.noise = false;
     s.sphere_mat.assign(d.n_spheres + 1, 0);
     for (size_t i = 0; i < d.n_spheres; ++i) {
         for (int a = 0; a < 3; ++a) s.spheres[4 * i + a] = d.spheres[i].center[a];
@@ -609,6 +610,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         s.mat_tex[2 * i + 1] = {(float)m.albedo2[0], (float)m.albedo2[1], (float)m.albedo2[2], 0};
         s.mat_scale[2 * i] = m.tex_scale, s.mat_scale[2 * i + 1] = 1.0 / m.tex_scale;  // f64::recip, material.rs:195
         if (m.texture != RT_TEX_SOLID) s.ext = true;
+        if (m.texture == RT_TEX_MARBLE) s.noise = true;
     }
     s.media.assign(std::max<size_t>(d.n_media, 1), DevMedium{});
     for (size_t k = 0; k < d.n_media; ++k) {
@@ -805,7 +807,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.spheres = upload(*s, s->spheres);
         s->dev.sphere_gate = upload(*s, s->sphere_gate);
         s->dev.quad_gate = upload(*s, s->quad_gate);
-        s->dev.ext = s->ext ? 1u : 0u;
+        s->dev.ext = s->ext ? (s->noise ? 3u : 1u) : 0u;
         s->dev.sphere_end = upload(*s, s->sphere_end);
         s->dev.n_media = (uint32_t)desc->n_media;
         s->dev.media = upload(*s, s->media);

@@ -744,6 +744,7 @@ __device__ __forceinline__ float perlin_turb(const float4* vec, const int32_t* p
 }
 // `n_out` is the sphere's outward unit normal (get_sphere_uv, surfaces.rs:108-118); u = v = 0 for triangles and
 // quads, which never set them (trace.rs:59-84).
+template <bool NOISE = true>
 __device__ __forceinline__ F3 texture_color(const DevScene& sc, int mat, F3 albedo, bool is_sphere, F3 n_out, D3 p) {
     const float4 t0 = sc.mat_tex[2 * mat];
     const int tex = __float_as_int(t0.x), index = __float_as_int(t0.y);
@@ -765,7 +766,7 @@ __device__ __forceinline__ F3 texture_color(const DevScene& sc, int mat, F3 albe
         const int s = (int)floorf(sc_ * u) + (int)floorf(sc_ * v);
         return (s & 1) == 0 ? albedo : odd;
     }
-    if (tex == 3) {  // NoiseTexture::marbled, material.rs:300-303
+    if (NOISE && tex == 3) {  // NoiseTexture::marbled, material.rs:300-303
         const F3 pf = tof(p);
         const float n = 0.5f * (1.0f + sinf((float)sc.mat_scale[2 * mat] * pf.z +
                                             10.0f * perlin_turb(sc.perlin_vec + 256 * index, sc.perlin_perm + 768 * index, pf)));
@@ -782,7 +783,7 @@ __device__ __forceinline__ F3 texture_color(const DevScene& sc, int mat, F3 albe
 }
 
 // `meta` is the hit slot's meta word (Closest::meta; tree hits only), `recs` the loose records as in loose_hits.
-template <bool DIRECT, bool EXT = false>
+template <bool DIRECT, bool EXT = false, bool NOISE = true>
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* recs, Ray& ray, const HitRec& hit,
                                              uint32_t meta, float tmin, Rng& rng, F3& thr, F3& lsum, uint32_t& depth,
                                              uint32_t max_depth, bool* retrace = nullptr, F3* emitted = nullptr) {
@@ -853,7 +854,7 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
     const bool front = dot(ray.d, n) < 0.0f;
     if (!front) n = neg(n);
 
-    const F3 albedo = EXT ? texture_color(sc, mat, f3(m), type == 0u, n_out, p) : f3(m);
+    const F3 albedo = EXT ? texture_color<NOISE>(sc, mat, f3(m), type == 0u, n_out, p) : f3(m);
     if (kind == 3) {  // DiffuseLight: emits on both faces, never scatters (material.rs:66-72, 94)
         if (EXT && retrace && ++depth < max_depth) {
             *retrace = true;

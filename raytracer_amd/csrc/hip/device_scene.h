@@ -74,7 +74,8 @@ struct DevScene {
                                 //   q and q+u+v, which is too small for a parallelogram whose sides share an axis
     const int32_t* sphere_mat;  // material id per sphere
     const int32_t* quad_mat;    // material id per quad
-    // textures and moving spheres (the EXT builds of the kernels; `ext` == 0 means none are present)
+    // textures and moving spheres (the EXT builds of the kernels; `ext` == 0 means none are present; bit 1: a noise
+    // texture is among them — the builds without one leave the Perlin code, and its registers, out)
     uint32_t ext;
     uint32_t tree_kind;         // what the render tree holds: 1 triangles only, 2 spheres only, 3 quads only, 0 a mix
     uint32_t n_media;

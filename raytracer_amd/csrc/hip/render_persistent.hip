@@ -36,6 +36,18 @@ constexpr int kBlock = RT_BLOCK;
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
+#ifndef RT_EXT_WAVES
+#define RT_EXT_WAVES 4
+#endif
+#ifndef RT_EXT_NOTREE_WAVES
+#define RT_EXT_NOTREE_WAVES 6  // EXT without a render tree and without a noise texture (84 VGPRs unforced; 5: -6 %, 8: -20 %)
+#endif
+#ifndef RT_EXT_PLAIN_WAVES
+#define RT_EXT_PLAIN_WAVES 5   // EXT with a single-kind render tree, without a noise texture (107 VGPRs unforced; 4: -9 %, 6: -32 %)
+#endif
+#ifndef RT_MEDIA_WAVES
+#define RT_MEDIA_WAVES 3  // the build with constant media: 168 VGPRs (4 waves spill 56 dwords: -8..-12 %; 2 waves: -24 %)
+#endif
 constexpr uint32_t kChunkStrata = 16;  // strata per chunk in the first phase (a chunk is 64 pixels x this many strata)
 constexpr int kPhases = 5;
 
@@ -156,8 +168,8 @@ __device__ __attribute__((noinline)) void draw_batch(const void* kernarg, float*
     if (EXT) wgen[kGenTime * 64u + lane] = cs.time;
 }
 
-template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE>
-__global__ __launch_bounds__(kBlock, (TREE == 4 && !EXT) ? RT_NOTREE_WAVES : (TREE != 0 && !EXT) ? RT_LEAN_WAVES : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE, bool NOISE = true>
+__global__ __launch_bounds__(kBlock, MEDIA ? RT_MEDIA_WAVES : (TREE == 4 && !EXT) ? RT_NOTREE_WAVES : (TREE != 0 && !EXT) ? RT_LEAN_WAVES : (EXT && !NOISE && TREE == 4) ? RT_EXT_NOTREE_WAVES : (EXT && !NOISE && TREE != 0) ? RT_EXT_PLAIN_WAVES : EXT ? RT_EXT_WAVES : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
@@ -268,12 +280,12 @@ __global__ __launch_bounds__(kBlock, (TREE == 4 && !EXT) ? RT_NOTREE_WAVES : (TR
                             break;
                         }
                         media_sample(ss, ray, 0.001f, rng, best, spans);
-                        alive = shade_bounce<DIRECT, EXT>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
+                        alive = shade_bounce<DIRECT, EXT, NOISE>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
                                                           max_depth, &again, &emitted);
                         light = again && best.h.slot > kMediumSlot && (emitted.x != 0.f || emitted.y != 0.f || emitted.z != 0.f);
                     } while (again && alive);
                 } else {
-                    alive = shade_bounce<DIRECT, EXT>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
+                    alive = shade_bounce<DIRECT, EXT, NOISE>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
                                                       max_depth);
                 }
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
@@ -429,7 +441,14 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
 #define RT_LAUNCH(EXT_, MEDIA_, TREE_)                                                                                  \
     hipLaunchKernelGGL((render_persistent_kernel<STATS, DIRECT, EXT_, MEDIA_, TREE_>), dim3(blocks), dim3(kBlock), lds, \
                        stream, sc, rp, plan, d_acc, counters, work_counter)
+#define RT_LAUNCH_PLAIN(TREE_)                                                                                          \
+    hipLaunchKernelGGL((render_persistent_kernel<STATS, DIRECT, true, false, TREE_, false>), dim3(blocks), dim3(kBlock), \
+                       lds, stream, sc, rp, plan, d_acc, counters, work_counter)
+    const bool noise = (sc.ext & 2u) != 0u;
     if (sc.ext && sc.n_media) RT_LAUNCH(true, true, 0);
+    else if (sc.ext && !noise && !sc.has_tree) RT_LAUNCH_PLAIN(4);
+    else if (sc.ext && !noise && sc.tree_kind == 2u) RT_LAUNCH_PLAIN(2);
+    else if (sc.ext && !noise) RT_LAUNCH_PLAIN(0);
     else if (sc.ext && !sc.has_tree) RT_LAUNCH(true, false, 4);
     else if (sc.ext && sc.tree_kind == 2u) RT_LAUNCH(true, false, 2);
     else if (sc.ext) RT_LAUNCH(true, false, 0);
@@ -439,6 +458,7 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
     else if (sc.tree_kind == 3u) RT_LAUNCH(false, false, 3);
     else RT_LAUNCH(false, false, 0);
 #undef RT_LAUNCH
+#undef RT_LAUNCH_PLAIN
 }
 
 static hipError_t launch_any(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,

@@ -13,6 +13,7 @@ ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--sampler", type=int, default=1)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--stats-sn", type=int, default=4, help="sn of the counting build's frame (the stage split is that frame's)")
 ap.add_argument("--slice", type=int, default=1, help="render strata k = 0 mod SLICE (the share of one of SLICE GPUs)")
 a = ap.parse_args()
 if a.stages:
@@ -26,7 +27,7 @@ for name in a.scenes:
     i = s.info()
     print(f"{name}: render tree nodes {i.render_nodes} depth {i.render_depth} maxleaf {i.render_max_leaf} loose {i.n_loose} "
           f"setup {i.build_ms:.0f} ms", flush=True)
-    _, st = s.render(w, h, 4, collect_stats=True, kernel=a.kernel, sampler=a.sampler)
+    _, st = s.render(w, h, a.stats_sn, collect_stats=True, kernel=a.kernel, sampler=a.sampler)
     print(f"  seg/sample {st.segments / st.samples:.2f} nodes/seg {st.node_visits / st.segments:.2f} "
           f"tris/seg {st.tri_tests / st.segments:.2f} sph/seg {st.sphere_tests / st.segments:.2f} "
           f"quad/seg {st.quad_tests / st.segments:.2f}", flush=True)
