@@ -715,6 +715,9 @@ __device__ __forceinline__ bool media_light_attempts(const DevScene& sc, const M
     return emits;
 }
 
+#ifndef RT_PERLIN_INLINE
+#define RT_PERLIN_INLINE __attribute__((noinline))
+#endif
 // ---- textures (EXT builds): Texture::color_at, material.rs:212-221
 // PerlinNoise::noise + trilinear_interp, material.rs:325-368
 __device__ __forceinline__ float perlin_noise(const float4* vec, const int32_t* perm, F3 p) {
@@ -733,7 +736,7 @@ __device__ __forceinline__ float perlin_noise(const float4* vec, const int32_t* 
     }
     return acc;
 }
-__device__ __forceinline__ float perlin_turb(const float4* vec, const int32_t* perm, F3 p) {  // material.rs:311-323
+__device__ RT_PERLIN_INLINE float perlin_turb(const float4* vec, const int32_t* perm, F3 p) {  // material.rs:311-323
     float acc = 0.f, weight = 1.f;
     for (int d = 0; d < 7; ++d) {
         acc += weight * perlin_noise(vec, perm, p);
