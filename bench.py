@@ -261,6 +261,8 @@ def main() -> None:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
+            # the reduce's blocks queue behind CU-filling render launches: let them go first when slots free up
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
             dist.init_process_group("nccl", device_id=dev)
 
     scene_file = os.path.join(ROOT, "scenes", f"{args.scene}.yaml")
