@@ -353,12 +353,28 @@ void check_device_tree(const std::vector<float>& bounds, const std::vector<int32
     if (covered != n || leaves != t.n_leaves) bad("leaves do not cover the primitives");
 }
 
+// Are the scene's spheres and quads tested by every ray ("loose") rather than put into the render tree?  Counted are
+// the surfaces of their own (a medium's boundary is not one: it is met through the medium).  Measured
+// (tools/loose_crossover.py, the example scenes): without triangles — no tree at all then, the shade-only build with
+// every lane busy — loose wins up to 32 of them (20: +19 %, 32: +5 %, 40: -6 %; the cornell example's 18 quads in
+// their closed box, where a tree culls nothing: 2.2x); beside a mesh the tree is there anyway, but the scene files'
+// ground spheres and room walls span it: teapot.yaml and cornell_lucy.yaml lose 55 % and 42 % with their six in the
+// tree, which also takes the general kernel build and its fourth wave.
+static bool loose_spheres_and_quads(const rt_scene_desc& d) {
+    size_t n = 0, triangles = 0;
+    for (size_t i = 0; i < d.n_surfaces; ++i) {
+        n += d.surfaces[i].type == RT_SURF_SPHERE || d.surfaces[i].type == RT_SURF_QUAD;
+        triangles += d.surfaces[i].type == RT_SURF_TRIANGLE;
+    }
+    return n <= (triangles ? kMaxLooseBesideMesh : kMaxLoose);
+}
+
 constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured: 2 beats 4 and 8 by 4-5 %)
 
 // The tree the render kernels traverse: triangles, plus spheres/quads when the scene has too many of them to
 // test "loose".  Independent of the reference-topology tree, so the two builds run side by side.
 void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
-    const bool loose_ok = d.n_spheres + d.n_quads <= kMaxLoose;
+    const bool loose_ok = loose_spheres_and_quads(d);
     std::vector<int32_t>& tree_ids = s.render_ids;
     tree_ids.clear();
     for (size_t i = 0; i < d.n_surfaces; ++i) {
@@ -423,7 +439,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     std::vector<int32_t> rank(n_surf);
     for (size_t i = 0; i < n_surf; ++i) rank[s.bvh.order[i]] = (int32_t)i;
 
-    const bool loose_ok = d.n_spheres + d.n_quads <= kMaxLoose;
+    const bool loose_ok = loose_spheres_and_quads(d);
     const std::vector<int32_t>& tree_ids = s.render_ids;
     s.loose.clear();
     for (size_t i = 0; i < n_surf; ++i) {

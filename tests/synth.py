@@ -18,7 +18,7 @@ def _mat(rng, kind=None):
 
 
 def many_prims(tmp_path, n_spheres=28, n_quads=5, with_mesh=True, seed=7):
-    """More than 16 spheres+quads, so they live in the render tree (f64 tests inside the leaf stage), next to
+    """More than 16 spheres+quads beside a mesh (more than 32 without one: n_spheres=40), so they live in the render tree (f64 tests inside the leaf stage), next to
     a small triangle mesh, a light and a hollow glass sphere (negative radius inside a positive one)."""
     rng = np.random.default_rng(seed)
     s = [CAM, "scene:\n  background: [0.5, 0.6, 0.8]\n  surfaces:\n"]
@@ -51,6 +51,26 @@ def many_prims(tmp_path, n_spheres=28, n_quads=5, with_mesh=True, seed=7):
         s.append("    - type: mesh\n      path: grid.obj\n      material: {type: metal, albedo: [0.9, 0.8, 0.6], fuzz: 0.05}\n"
                  "      transform:\n        - {type: translate, dir: [0, 1.6, 0]}\n")
     p = tmp_path / "many.yaml"
+    p.write_text("".join(s))
+    return str(p)
+
+
+def many_quads(tmp_path, n=40, seed=3):
+    """A floor, a light and n upright panels: more than 32 quads and nothing else, so the render tree holds quads only
+    (the kernels' TREE = 3 build)."""
+    rng = np.random.default_rng(seed)
+    s = [CAM, "scene:\n  background: [0.5, 0.6, 0.8]\n  surfaces:\n"]
+    s.append("    - type: quad\n      position: [-6, 0, -6]\n      sides: [[12, 0, 0], [0, 0, 12]]\n"
+             "      material: {type: lambertian, albedo: [0.5, 0.5, 0.5]}\n")
+    s.append("    - type: quad\n      position: [-1, 3, -1]\n      sides: [[2, 0, 0], [0, 0, 2]]\n"
+             f"      material: {_mat(rng, 'light')}\n")
+    for k in range(n):
+        x, z, turn = rng.uniform(-4, 4), rng.uniform(-4, 3), rng.uniform(0, np.pi)
+        wdt, hgt = rng.uniform(0.3, 0.9), rng.uniform(0.3, 1.2)
+        s.append(f"    - type: quad\n      position: [{x:.3f}, 0, {z:.3f}]\n"
+                 f"      sides: [[{wdt * np.cos(turn):.3f}, 0, {wdt * np.sin(turn):.3f}], [0, {hgt:.3f}, 0]]\n"
+                 f"      material: {_mat(rng)}\n")
+    p = tmp_path / "panels.yaml"
     p.write_text("".join(s))
     return str(p)
 

@@ -1,5 +1,5 @@
 """Edge cases of the render path that no shipped scene reaches, on synthetic scene files (tests/synth.py):
-spheres and quads living in the render tree (scenes with more than 16 of them), trees deeper than the
+spheres and quads living in the render tree (scenes with more than 16 of them beside a mesh, 32 without one), trees deeper than the
 smallest traversal-stack build, --no-bvh renders, ranks without strata, 1 spp and odd frame sizes.
 Same bars as test_gpu_parity.py.  Needs an MI355X:  pytest -m gpu."""
 import numpy as np
@@ -27,7 +27,7 @@ def test_spheres_and_quads_inside_the_render_tree(ra, ref, tmp_path):
     w, h, sn = 120, 80, 4
     scene = ra.Scene(ra.load_scene(path, w / h), 0)
     info = scene.info()
-    assert info.n_loose == 0 and info.n_surfaces > 200  # 36 spheres+quads > 16: all of them in the tree
+    assert info.n_loose == 0 and info.n_surfaces > 200  # 36 spheres+quads > 16 beside a mesh: all of them in the tree
     oracle = ref.RefScene.from_yaml(path, w / h)
     _primary_parity(scene, oracle, w, h)
     for sampler in (0, 1):
@@ -41,13 +41,12 @@ def test_spheres_and_quads_inside_the_render_tree(ra, ref, tmp_path):
 
 def test_spheres_only_render_tree(ra, ref, tmp_path):
     """A tree of nothing but spheres — with the hollow glass ball: a negative radius behind its leaf's gate, Q8 —
-    runs a build of its own (TREE = 2), like the triangles-only mesh scenes (the quads-only one is the cornell
-    example's, tests/test_examples.py)."""
-    path = synth.many_prims(tmp_path, n_spheres=28, n_quads=0, with_mesh=False)
+    runs a build of its own (TREE = 2), like the triangles-only mesh scenes and the quads-only one below."""
+    path = synth.many_prims(tmp_path, n_spheres=40, n_quads=0, with_mesh=False)
     w, h, sn = 120, 80, 4
     scene = ra.Scene(ra.load_scene(path, w / h), 0)
     info = scene.info()
-    assert info.n_surfaces == 31 and info.n_loose == 0
+    assert info.n_surfaces == 43 and info.n_loose == 0  # more than 32 and no mesh: a tree
     oracle = ref.RefScene.from_yaml(path, w / h)
     _primary_parity(scene, oracle, w, h)
     for sampler in (0, 1):
@@ -257,14 +256,51 @@ def test_two_renders_of_one_scene_in_flight_on_two_streams(ra):
     s.close()
 
 
+def test_quads_only_render_tree(ra, ref, tmp_path):
+    """A tree of nothing but quads (TREE = 3): 42 of them — up to 32 spheres and quads without a mesh are tested loose,
+    as the cornell example's 18 are."""
+    path = synth.many_quads(tmp_path, 40)
+    w, h, sn = 120, 80, 4
+    scene = ra.Scene(ra.load_scene(path, w / h), 0)
+    info = scene.info()
+    assert info.n_surfaces == 42 and info.n_loose == 0 and info.render_nodes > 20
+    oracle = ref.RefScene.from_yaml(path, w / h)
+    _primary_parity(scene, oracle, w, h)
+    for sampler in (0, 1):
+        want, _ = oracle.render(w, h, sn, threads=16, sampler=sampler)
+        for kernel in (0, 1, 2):
+            img, st = scene.render(w, h, sn, kernel=kernel, sampler=sampler, collect_stats=True)
+            _check_image(img, want, sn * sn, f"quads only, kernel {kernel} sampler {sampler}")
+            assert st.tri_tests == 0 and st.sphere_tests == 0 and st.quad_tests > 0
+    scene.close()
+
+
+def test_up_to_32_loose_without_a_mesh(ra, ref, tmp_path):
+    """31 spheres and no triangle: no render tree at all, every sphere tested by every ray (the shade-only build)."""
+    path = synth.many_prims(tmp_path, n_spheres=28, n_quads=0, with_mesh=False)
+    w, h, sn = 120, 80, 4
+    scene = ra.Scene(ra.load_scene(path, w / h), 0)
+    info = scene.info()
+    assert info.n_surfaces == 31 and info.n_loose == 31 and info.render_nodes == 0
+    oracle = ref.RefScene.from_yaml(path, w / h)
+    _primary_parity(scene, oracle, w, h)
+    for sampler in (0, 1):
+        want, _ = oracle.render(w, h, sn, threads=16, sampler=sampler)
+        for kernel in (0, 1, 2):
+            img, st = scene.render(w, h, sn, kernel=kernel, sampler=sampler, collect_stats=True)
+            _check_image(img, want, sn * sn, f"31 loose, kernel {kernel} sampler {sampler}")
+            assert st.node_visits == 0 and st.sphere_tests > 0
+    scene.close()
+
+
 def test_single_leaf_trees_of_one_kind(ra, ref, tmp_path):
     """--no-bvh on a spheres-only tree: the synthetic root's dummy slot is read by the spheres-only build as a
     sphere — a NaN-radius one that no ray can hit (api.cpp flatten_render)."""
-    path = synth.many_prims(tmp_path, n_spheres=28, n_quads=0, with_mesh=False)
+    path = synth.many_prims(tmp_path, n_spheres=40, n_quads=0, with_mesh=False)
     w, h, sn = 96, 64, 3
     a = ra.Scene(ra.load_scene(path, w / h, True), 0)
     b = ra.Scene(ra.load_scene(path, w / h, False), 0)
-    assert b.info().render_max_leaf == 31
+    assert b.info().render_max_leaf == 43
     ia, _ = a.render(w, h, sn)
     ib, _ = b.render(w, h, sn)
     assert _same_image(ia, ib, sn * sn)
