@@ -1,6 +1,7 @@
 // C ABI (include/rt.h): scene flattening + upload, kernel launches, error plumbing.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <csignal>
 #include <execinfo.h>
@@ -13,6 +14,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/rt.h"
@@ -114,6 +116,7 @@ struct rt_scene {
     std::vector<uint4> nodes;
     std::vector<float4> prims, tri_shade, materials;
     std::vector<int4> loose;
+    std::vector<char> is_loose;  // per surface: tested by every ray instead of living in the render tree
     std::vector<uint4> loose_rec;
     std::vector<int32_t> render_ids;  // surfaces that live in the render tree
     std::vector<double> sphere_gate, quad_gate, sphere_end, mat_scale;
@@ -353,20 +356,43 @@ void check_device_tree(const std::vector<float>& bounds, const std::vector<int32
     if (covered != n || leaves != t.n_leaves) bad("leaves do not cover the primitives");
 }
 
-// Are the scene's spheres and quads tested by every ray ("loose") rather than put into the render tree?  Counted are
-// the surfaces of their own (a medium's boundary is not one: it is met through the medium).  Measured
+// Which of the scene's spheres and quads are tested by every ray ("loose") rather than put into the render tree.
+// Counted are the surfaces of their own (a medium's boundary is not one: it is met through the medium).  Measured
 // (tools/loose_crossover.py, the example scenes): without triangles — no tree at all then, the shade-only build with
 // every lane busy — loose wins up to 32 of them (20: +19 %, 32: +5 %, 40: -6 %; the cornell example's 18 quads in
 // their closed box, where a tree culls nothing: 2.2x); beside a mesh the tree is there anyway, but the scene files'
 // ground spheres and room walls span it: teapot.yaml and cornell_lucy.yaml lose 55 % and 42 % with their six in the
-// tree, which also takes the general kernel build and its fourth wave.
-static bool loose_spheres_and_quads(const rt_scene_desc& d) {
-    size_t n = 0, triangles = 0;
+// tree, which also takes the general kernel build and its fourth wave.  A scene with more than that keeps its giants
+// loose all the same — a sphere or quad whose box is at least half as large (by area) as the box of everything
+// smaller than it, like the radius-1000 ground of one-weekend: inside the tree it would stretch the root over the
+// whole sky, and no ray would be spared the traversal by the bounds test.
+static double box_area(const Aabb& b) {
+    const V3 l = b.hi - b.lo;
+    return 2.0 * (l.x * l.y + l.y * l.z + l.z * l.x);
+}
+static std::vector<char> loose_surfaces(const rt_scene_desc& d) {
+    std::vector<char> loose(d.n_surfaces, 0);
+    std::vector<std::pair<double, size_t>> cand;  // (box area, surface)
+    Aabb triangles_box = Aabb::empty();
+    size_t triangles = 0;
     for (size_t i = 0; i < d.n_surfaces; ++i) {
-        n += d.surfaces[i].type == RT_SURF_SPHERE || d.surfaces[i].type == RT_SURF_QUAD;
-        triangles += d.surfaces[i].type == RT_SURF_TRIANGLE;
+        const int32_t type = d.surfaces[i].type;
+        if (type == RT_SURF_SPHERE || type == RT_SURF_QUAD) cand.push_back({box_area(true_bounds(d, d.surfaces[i])), i});
+        if (type == RT_SURF_TRIANGLE) triangles_box = triangles_box.merge(true_bounds(d, d.surfaces[i])), ++triangles;
     }
-    return n <= (triangles ? kMaxLooseBesideMesh : kMaxLoose);
+    if (cand.size() <= (triangles ? kMaxLooseBesideMesh : kMaxLoose)) {
+        for (const auto& c : cand) loose[c.second] = 1;
+        return loose;
+    }
+    std::stable_sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    std::vector<Aabb> rest(cand.size() + 1);  // rest[k]: the box of candidates k.. and of the triangles
+    rest[cand.size()] = triangles_box;
+    for (size_t k = cand.size(); k-- > 0;) rest[k] = rest[k + 1].merge(true_bounds(d, d.surfaces[cand[k].second]));
+    for (size_t k = 0; k < std::min<size_t>(cand.size(), kMaxLooseBesideMesh); ++k) {
+        if (!(cand[k].first >= 0.5 * box_area(rest[k + 1]))) break;
+        loose[cand[k].second] = 1;
+    }
+    return loose;
 }
 
 constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured: 2 beats 4 and 8 by 4-5 %)
@@ -374,12 +400,12 @@ constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured:
 // The tree the render kernels traverse: triangles, plus spheres/quads when the scene has too many of them to
 // test "loose".  Independent of the reference-topology tree, so the two builds run side by side.
 void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
-    const bool loose_ok = loose_spheres_and_quads(d);
+    s.is_loose = loose_surfaces(d);
     std::vector<int32_t>& tree_ids = s.render_ids;
     tree_ids.clear();
     for (size_t i = 0; i < d.n_surfaces; ++i) {
         if (d.surfaces[i].type == RT_SURF_MEDIUM) continue;  // media are evaluated after the surface trace
-        if (d.surfaces[i].type == RT_SURF_TRIANGLE || !loose_ok) tree_ids.push_back((int32_t)i);
+        if (!s.is_loose[i]) tree_ids.push_back((int32_t)i);
     }
     Bvh& rb = s.render_bvh;
     const uint32_t max_leaf = getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : kRenderLeaf;
@@ -439,13 +465,11 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     std::vector<int32_t> rank(n_surf);
     for (size_t i = 0; i < n_surf; ++i) rank[s.bvh.order[i]] = (int32_t)i;
 
-    const bool loose_ok = loose_spheres_and_quads(d);
     const std::vector<int32_t>& tree_ids = s.render_ids;
     s.loose.clear();
     for (size_t i = 0; i < n_surf; ++i) {
         const rt_surface_ref& ref = d.surfaces[i];
-        if (ref.type != RT_SURF_TRIANGLE && ref.type != RT_SURF_MEDIUM && loose_ok)
-            s.loose.push_back(int4{ref.type, ref.index, rank[i], (int32_t)i});
+        if (s.is_loose[i]) s.loose.push_back(int4{ref.type, ref.index, rank[i], (int32_t)i});
     }
     Bvh& rb = s.render_bvh;
     const size_t n_tree = tree_ids.size();

@@ -27,7 +27,8 @@ def test_spheres_and_quads_inside_the_render_tree(ra, ref, tmp_path):
     w, h, sn = 120, 80, 4
     scene = ra.Scene(ra.load_scene(path, w / h), 0)
     info = scene.info()
-    assert info.n_loose == 0 and info.n_surfaces > 200  # 36 spheres+quads > 16 beside a mesh: all of them in the tree
+    # 36 spheres+quads > 16 beside a mesh: in the tree, all but the ground sphere (a giant stays loose, api.cpp loose_surfaces)
+    assert info.n_loose == 1 and info.n_surfaces > 200
     oracle = ref.RefScene.from_yaml(path, w / h)
     _primary_parity(scene, oracle, w, h)
     for sampler in (0, 1):
@@ -46,7 +47,7 @@ def test_spheres_only_render_tree(ra, ref, tmp_path):
     w, h, sn = 120, 80, 4
     scene = ra.Scene(ra.load_scene(path, w / h), 0)
     info = scene.info()
-    assert info.n_surfaces == 43 and info.n_loose == 0  # more than 32 and no mesh: a tree
+    assert info.n_surfaces == 43 and info.n_loose == 1  # more than 32 and no mesh: a tree (the ground stays loose)
     oracle = ref.RefScene.from_yaml(path, w / h)
     _primary_parity(scene, oracle, w, h)
     for sampler in (0, 1):
@@ -263,7 +264,7 @@ def test_quads_only_render_tree(ra, ref, tmp_path):
     w, h, sn = 120, 80, 4
     scene = ra.Scene(ra.load_scene(path, w / h), 0)
     info = scene.info()
-    assert info.n_surfaces == 42 and info.n_loose == 0 and info.render_nodes > 20
+    assert info.n_surfaces == 42 and info.n_loose == 1 and info.render_nodes > 20  # the floor stays loose
     oracle = ref.RefScene.from_yaml(path, w / h)
     _primary_parity(scene, oracle, w, h)
     for sampler in (0, 1):
@@ -300,7 +301,7 @@ def test_single_leaf_trees_of_one_kind(ra, ref, tmp_path):
     w, h, sn = 96, 64, 3
     a = ra.Scene(ra.load_scene(path, w / h, True), 0)
     b = ra.Scene(ra.load_scene(path, w / h, False), 0)
-    assert b.info().render_max_leaf == 43
+    assert b.info().render_max_leaf == 42
     ia, _ = a.render(w, h, sn)
     ib, _ = b.render(w, h, sn)
     assert _same_image(ia, ib, sn * sn)
