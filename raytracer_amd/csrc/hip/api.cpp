@@ -395,7 +395,9 @@ static std::vector<char> loose_surfaces(const rt_scene_desc& d) {
     return loose;
 }
 
-constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured: 2 beats 4 and 8 by 4-5 %)
+constexpr uint32_t kRenderLeaf = 2;   // leaf size of the render tree (measured: 2 beats 4 and 8 by 4-5 %) ...
+constexpr uint32_t kRenderLeafF64 = 1;  // ... and 1 when it holds spheres or quads, whose f64 tests cost three box tests
+                                        //     (final-scene +8.5 %, random-spheres +5 %, one-weekend +2 % over 2)
 
 // The tree the render kernels traverse: triangles, plus spheres/quads when the scene has too many of them to
 // test "loose".  Independent of the reference-topology tree, so the two builds run side by side.
@@ -408,7 +410,9 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
         if (!s.is_loose[i]) tree_ids.push_back((int32_t)i);
     }
     Bvh& rb = s.render_bvh;
-    const uint32_t max_leaf = getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : kRenderLeaf;
+    bool only_triangles = true;
+    for (int32_t id : tree_ids) only_triangles = only_triangles && d.surfaces[id].type == RT_SURF_TRIANGLE;
+    const uint32_t max_leaf = getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : (only_triangles ? kRenderLeaf : kRenderLeafF64);
     if (d.use_bvh && build_device >= 0) {
         // opt-in (use_bvh == 2 or RT_BUILD=device): the same builder as build_render_bvh, level by level on the GPU.
         // Its input is each primitive's f32 box, rounded outward from the bounds the host builder uses.
