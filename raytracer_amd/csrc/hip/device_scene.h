@@ -16,7 +16,10 @@ constexpr int kNoChild = 0x7fffffff;  // "empty" child of the synthetic root whe
 #define RT_MAX_LOOSE 32
 #endif
 constexpr uint32_t kMaxLoose = RT_MAX_LOOSE;    // at most this many spheres+quads are tested by every ray ("loose") ...
-constexpr uint32_t kMaxLooseBesideMesh = 16;    // ... and this many when the scene has triangles (api.cpp, loose_spheres_and_quads)
+#ifndef RT_MAX_LOOSE_MESH
+#define RT_MAX_LOOSE_MESH 16
+#endif
+constexpr uint32_t kMaxLooseBesideMesh = RT_MAX_LOOSE_MESH;    // ... and this many when the scene has triangles (api.cpp, loose_spheres_and_quads)
 constexpr uint32_t kLooseRecQuads = 11;  // uint4 per loose record: {type, index, rank, material} + 20 doubles
 
 // f64 records for the exact-parity kernel (array of structs; speed is irrelevant there).

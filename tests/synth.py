@@ -55,6 +55,29 @@ def many_prims(tmp_path, n_spheres=28, n_quads=5, with_mesh=True, seed=7):
     return str(p)
 
 
+def room(tmp_path, n_spheres=20, seed=5):
+    """Six walls around n small spheres and a small mesh: more spheres and quads than stay loose beside a mesh, so the
+    small ones go into the render tree — the walls, each a third of the room's box, must not (api.cpp loose_surfaces)."""
+    rng = np.random.default_rng(seed)
+    s = [CAM, "scene:\n  background: [0, 0, 0]\n  surfaces:\n"]
+    walls = [([-5, 0, -5], [10, 0, 0], [0, 0, 15]), ([-5, 6, -5], [10, 0, 0], [0, 0, 15]),   # floor, ceiling
+             ([-5, 0, -5], [0, 6, 0], [0, 0, 15]), ([5, 0, -5], [0, 6, 0], [0, 0, 15]),      # left, right
+             ([-5, 0, -5], [10, 0, 0], [0, 6, 0]), ([-5, 0, 10], [10, 0, 0], [0, 6, 0])]     # back, front (behind the camera)
+    for k, (q, u, v) in enumerate(walls):
+        kind = "light" if k == 1 else "lambertian"
+        s.append(f"    - type: quad\n      position: {q}\n      sides: [{u}, {v}]\n      material: {_mat(rng, kind)}\n")
+    for k in range(n_spheres):
+        x, z, r = rng.uniform(-4, 4), rng.uniform(-4, 3), rng.uniform(0.15, 0.45)
+        s.append(f"    - type: sphere\n      radius: {r:.3f}\n      position: [{x:.3f}, {r:.3f}, {z:.3f}]\n"
+                 f"      material: {_mat(rng)}\n")
+    (tmp_path / "tri.obj").write_text("v -1 0 0\nv 1 0 0\nv 0 1.5 0\nv 0 0.5 1\nf 1 2 3\nf 1 2 4\nf 2 3 4\nf 1 3 4\n")
+    s.append("    - type: mesh\n      path: tri.obj\n      material: {type: metal, albedo: [0.9, 0.8, 0.6], fuzz: 0.05}\n"
+             "      transform:\n        - {type: translate, dir: [0, 0.2, 1]}\n")
+    p = tmp_path / "room.yaml"
+    p.write_text("".join(s))
+    return str(p)
+
+
 def many_quads(tmp_path, n=40, seed=3):
     """A floor, a light and n upright panels: more than 32 quads and nothing else, so the render tree holds quads only
     (the kernels' TREE = 3 build)."""

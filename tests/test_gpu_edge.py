@@ -257,6 +257,23 @@ def test_two_renders_of_one_scene_in_flight_on_two_streams(ra):
     s.close()
 
 
+def test_walls_stay_loose_beside_spheres_in_the_tree(ra, ref, tmp_path):
+    """A closed room: its six walls are giants and stay loose, 20 small spheres share the render tree with a mesh."""
+    path = synth.room(tmp_path)
+    w, h, sn = 120, 80, 4
+    scene = ra.Scene(ra.load_scene(path, w / h), 0)
+    assert scene.info().n_loose == 6
+    oracle = ref.RefScene.from_yaml(path, w / h)
+    _primary_parity(scene, oracle, w, h)
+    for sampler in (0, 1):
+        want, _ = oracle.render(w, h, sn, threads=16, sampler=sampler)
+        for kernel in (0, 1, 2):
+            img, st = scene.render(w, h, sn, kernel=kernel, sampler=sampler, collect_stats=True)
+            _check_image(img, want, sn * sn, f"room, kernel {kernel} sampler {sampler}")
+            assert st.quad_tests > 0 and st.sphere_tests > 0 and st.tri_tests > 0
+    scene.close()
+
+
 def test_quads_only_render_tree(ra, ref, tmp_path):
     """A tree of nothing but quads (TREE = 3): 42 of them — up to 32 spheres and quads without a mesh are tested loose,
     as the cornell example's 18 are."""

@@ -228,6 +228,8 @@ def test_render_tree_depth_is_capped_and_small_prims_move_into_the_tree(ra, tmp_
     assert 41 <= deep.render_depth <= 56  # SAH alone would go ~1500 levels deep on this cluster
     many = ra.Scene(ra.load_scene(synth.many_prims(tmp_path), 1.5), ra.RT_DEVICE_NONE).info()
     assert many.n_loose == 1 and many.n_surfaces == 1 + 28 + 2 + 5 + 200  # the ground sphere, a giant, stays loose
+    room = ra.Scene(ra.load_scene(synth.room(tmp_path), 1.5), ra.RT_DEVICE_NONE).info()
+    assert room.n_loose == 6 and room.n_surfaces == 6 + 20 + 4  # the walls stay loose, the 20 small spheres do not
 
 
 def test_obj_normals_and_first_model_only(ra, tmp_path):
