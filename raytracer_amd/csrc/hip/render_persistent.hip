@@ -475,9 +475,12 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
                                     uint32_t n_cus, float* d_acc, float* d_rgb_sum, DevCounters* counters,
                                     uint32_t* work_counter, bool stats, hipStream_t stream) {
     PersistentPlan plan;
-    // (36 for the triangle meshes; trees of spheres and quads, whose rays nearly all enter the tree, take 48:
-    // one-weekend +3.5 %, random-spheres +6 %, final-scene +3 %)
-    plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T")) : (sc.tree_kind == 1u ? 36 : 48);
+    // (36 for the large triangle meshes, 44 for the small ones — trees of up to 18 levels, which stay in the caches: a
+    // node trip is then cheap beside a shade trip, and the shade stage had better wait for more lanes: teapot.yaml
+    // +3.3 %, dual.yaml +1.6 %, where lucy.yaml would lose 2.7 %; trees of spheres and quads, whose rays nearly all
+    // enter the tree, take 48: one-weekend +3.5 %, random-spheres +6 %, final-scene +3 %)
+    plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T"))
+                           : (sc.tree_kind != 1u ? 48 : (tree_depth <= 18u ? 44 : 36));
     plan.node_bias = getenv("RT_NODE_BIAS") ? atoi(getenv("RT_NODE_BIAS")) : 2;
     plan.tiles_x = (rp.width + 7u) >> 3;
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
