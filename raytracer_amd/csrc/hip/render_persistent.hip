@@ -168,8 +168,17 @@ __device__ __attribute__((noinline)) void draw_batch(const void* kernarg, float*
     if (EXT) wgen[kGenTime * 64u + lane] = cs.time;
 }
 
+// Waves per SIMD each build is compiled for (the register budget that follows from it): every one measured, see the
+// macros above and DESIGN §4.1 "builds".
+constexpr int waves_per_simd(bool ext, bool media, int tree, bool noise) {
+    if (media) return RT_MEDIA_WAVES;
+    if (!ext) return tree == 4 ? RT_NOTREE_WAVES : (tree != 0 ? RT_LEAN_WAVES : RT_MIN_WAVES);
+    if (noise) return RT_EXT_WAVES;
+    return tree == 4 ? RT_EXT_NOTREE_WAVES : (tree != 0 ? RT_EXT_PLAIN_WAVES : RT_EXT_WAVES);
+}
+
 template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE, bool NOISE = true>
-__global__ __launch_bounds__(kBlock, MEDIA ? RT_MEDIA_WAVES : (TREE == 4 && !EXT) ? RT_NOTREE_WAVES : (TREE != 0 && !EXT) ? RT_LEAN_WAVES : (EXT && !NOISE && TREE == 4) ? RT_EXT_NOTREE_WAVES : (EXT && !NOISE && TREE != 0) ? RT_EXT_PLAIN_WAVES : EXT ? RT_EXT_WAVES : RT_MIN_WAVES) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+__global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
