@@ -126,18 +126,20 @@ def read_obj_first_model(path):
     pos, nrm, faces, nfaces = [], [], [], []
     with opener(path, "rt") as f:
         for line in f:
-            if line.startswith("v "):
-                pos.append(line.split()[1:4])
-            elif line.startswith("vn "):
-                nrm.append(line.split()[1:4])
-            elif line.startswith("f "):
-                toks = [tok.split("/") for tok in line.split()[1:]]
+            tok = line.split()  # tobj: the keyword is the first whitespace-separated token of the line
+            key = tok[0] if tok else ""
+            if key == "v":
+                pos.append(tok[1:4])
+            elif key == "vn":
+                nrm.append(tok[1:4])
+            elif key == "f":
+                toks = [t.split("/") for t in tok[1:]]
                 if len(toks) != 3:
                     raise ValueError("only triangles are supported")
                 faces.append([int(t[0]) for t in toks])
                 if len(toks[0]) == 3 and toks[0][2]:
                     nfaces.append([int(t[2]) for t in toks])
-            elif line[:2] in ("o ", "g ") and faces:
+            elif key in ("o", "g") and faces:  # a bare `g` / `o` line too
                 break  # only the first model is used (load.rs:225-229)
     pos32 = np.array(pos, dtype=np.float32)  # numpy parses decimal -> f32 with correct rounding
 

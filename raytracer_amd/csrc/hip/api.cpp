@@ -3,9 +3,6 @@
 
 #include <algorithm>
 #include <chrono>
-#include <csignal>
-#include <execinfo.h>
-#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -20,6 +17,7 @@
 #include "../../../include/rt.h"
 #include "../host/bvh_build.h"
 #include "../host/scene_host.h"
+#include "../host/worker.h"
 #include "device_scene.h"
 #include "kernels.h"
 #include "wavefront.h"
@@ -129,8 +127,21 @@ struct rt_scene {
     bool noise = false;  // a Perlin-noise texture among them (the kernels' NOISE builds)
     std::vector<double> spheres, quads;
     std::vector<int32_t> sphere_mat, quad_mat, mat_kind, slot_surface;
+    // The exact-parity kernel's f64 arrays (the un-rounded reference-topology tree) are parity-only data: flattened
+    // and uploaded at the first rt_primary_hits(precision = 64), not at scene creation.  Until then the scene keeps
+    // what that flattening reads beside the tree itself — the caller's rt_scene_desc need not outlive the call:
+    struct Reference64Source {
+        std::vector<rt_surface_ref> surfaces;
+        std::vector<double> tri_v;  // 9 per triangle
+        std::vector<rt_sphere> spheres;
+        std::vector<rt_quad> quads;
+    };
+    std::unique_ptr<Reference64Source> ref64_source;  // released once the arrays are on the device
     std::vector<Node64> nodes64;
     std::vector<Prim64> prims64;
+    bool ref64_ready = false;
+    // orders rt_render_device_noalloc calls on this scene's device (they share one static scratch array per GPU)
+    hipEvent_t* noalloc_done = nullptr;
 
     ~rt_scene() {
         if (device >= 0) {
@@ -151,31 +162,6 @@ struct rt_scene {
 };
 
 namespace {
-
-// Debugging aid (RT_SEGV_TRACE=1): the faulting thread's stack on SIGSEGV / SIGBUS / SIGABRT, on an alternate stack
-// so that a stack overflow prints too.
-struct SegvTrace {
-    static void handler(int sig) {
-        void* frames[64];
-        const int n = backtrace(frames, 64);
-        const char msg[] = "librt_amd: fatal signal, stack of the faulting thread:\n";
-        (void)!write(2, msg, sizeof msg - 1);
-        backtrace_symbols_fd(frames, n, 2);
-        signal(sig, SIG_DFL);
-        raise(sig);
-    }
-    SegvTrace() {
-        if (!getenv("RT_SEGV_TRACE")) return;
-        static char alt[1 << 16];
-        stack_t ss{};
-        ss.ss_sp = alt, ss.ss_size = sizeof alt;
-        sigaltstack(&ss, nullptr);  // (this thread's; other threads fall back to their own stack)
-        struct sigaction sa{};
-        sa.sa_handler = handler;
-        sa.sa_flags = SA_ONSTACK;
-        for (int sig : {SIGSEGV, SIGBUS, SIGABRT}) sigaction(sig, &sa, nullptr);
-    }
-} g_segv_trace;
 
 template <typename T>
 const T* upload(rt_scene& s, const std::vector<T>& v) {
@@ -246,11 +232,23 @@ struct FlatTree {
     }
 };
 
+// What flatten_reference64 reads of the caller's scene description (kept with the scene until it has run).
+void capture_reference64_source(const rt_scene_desc& d, rt_scene& s) {
+    auto src = std::make_unique<rt_scene::Reference64Source>();
+    src->surfaces.assign(d.surfaces, d.surfaces + d.n_surfaces);
+    src->tri_v.resize(9 * d.n_triangles);
+    for (size_t i = 0; i < d.n_triangles; ++i) std::memcpy(&src->tri_v[9 * i], d.triangles[i].v, 9 * sizeof(double));
+    src->spheres.assign(d.spheres, d.spheres + d.n_spheres);
+    src->quads.assign(d.quads, d.quads + d.n_quads);
+    s.ref64_source = std::move(src);
+}
+
 // Reference-topology tree -> f64 arrays of the exact-parity kernel.  Inner nodes keep their children's boxes;
 // leaves become runs of slots in the in-order sequence, closed by a last-in-leaf flag.
-void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
+void flatten_reference64(rt_scene& s) {
     const Bvh& bvh = s.bvh;
-    const size_t n_surf = d.n_surfaces;
+    const rt_scene::Reference64Source& d = *s.ref64_source;
+    const size_t n_surf = d.surfaces.size();
     const FlatTree ft(bvh);
     s.nodes64.assign(ft.n_dev_nodes, Node64{});
     auto put = [&](size_t node, int c, const Aabb& b, int32_t ref) {
@@ -278,9 +276,7 @@ void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
         Prim64& p64 = s.prims64[slot];
         p64.type = ref.type, p64.last = last[slot], p64.surface = sid;
         if (ref.type == RT_SURF_TRIANGLE) {
-            const rt_triangle& t = d.triangles[ref.index];
-            for (int k = 0; k < 3; ++k)
-                for (int a = 0; a < 3; ++a) p64.a[3 * k + a] = t.v[k][a];
+            std::memcpy(p64.a, &d.tri_v[9 * (size_t)ref.index], 9 * sizeof(double));
         } else if (ref.type == RT_SURF_MEDIUM) {
             // no deterministic hit: the parity AOV sees surfaces only (prim_hit knows no type 3)
         } else if (ref.type == RT_SURF_SPHERE) {
@@ -296,11 +292,15 @@ void flatten_reference64(const rt_scene_desc& d, rt_scene& s) {
             p64.a[3] = q.d;
         }
     }
-    s.info.n_surfaces = n_surf;
-    s.info.n_nodes = bvh.nodes.size();
-    s.info.n_leaves = bvh.n_leaves;
-    s.info.max_depth = bvh.max_depth;
-    s.info.max_leaf_size = bvh.max_leaf_size;
+}
+
+// the reference-topology tree's figures (rt_scene_info)
+void reference_tree_info(rt_scene& s, size_t n_surfaces) {
+    s.info.n_surfaces = n_surfaces;
+    s.info.n_nodes = s.bvh.nodes.size();
+    s.info.n_leaves = s.bvh.n_leaves;
+    s.info.max_depth = s.bvh.max_depth;
+    s.info.max_leaf_size = s.bvh.max_leaf_size;
 }
 
 // A tree that came back from the GPU is checked before anything traverses it: every primitive in exactly one leaf,
@@ -411,7 +411,7 @@ constexpr uint32_t kRenderLeafF64 = 1;  // ... and 1 when it holds spheres or qu
 
 // The tree the render kernels traverse: triangles, plus spheres/quads when the scene has too many of them to
 // test "loose".  Independent of the reference-topology tree, so the two builds run side by side.
-void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
+void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device, const BuildKnobs& knobs) {
     s.is_loose = loose_surfaces(d);
     std::vector<int32_t>& tree_ids = s.render_ids;
     tree_ids.clear();
@@ -422,7 +422,7 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
     Bvh& rb = s.render_bvh;
     bool only_triangles = true;
     for (int32_t id : tree_ids) only_triangles = only_triangles && d.surfaces[id].type == RT_SURF_TRIANGLE;
-    const uint32_t max_leaf = getenv("RT_LEAF") ? (uint32_t)atoi(getenv("RT_LEAF")) : (only_triangles ? kRenderLeaf : kRenderLeafF64);
+    const uint32_t max_leaf = knobs.leaf ? knobs.leaf : (only_triangles ? kRenderLeaf : kRenderLeafF64);
     if (d.use_bvh && build_device >= 0) {
         // opt-in (use_bvh == 2 or RT_BUILD=device): the same builder as build_render_bvh, level by level on the GPU.
         // Its input is each primitive's f32 box, rounded outward from the bounds the host builder uses.
@@ -438,10 +438,10 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device) {
             }
         }
         if (hipSetDevice(build_device) != hipSuccess) throw std::runtime_error("device BVH build: cannot select the device");
-        build_render_bvh_device(bounds, tree_ids, max_leaf, rb);
+        build_render_bvh_device(bounds, tree_ids, max_leaf, knobs, rb);
         check_device_tree(bounds, tree_ids, rb);
     } else if (d.use_bvh) {
-        build_render_bvh(d, tree_ids, max_leaf, rb);
+        build_render_bvh(d, tree_ids, max_leaf, knobs.traversal_cost, rb);
     } else {  // --no-bvh: one leaf, every surface tested by every ray (main.rs:60-65)
         rb = Bvh{};
         rb.order = tree_ids;
@@ -755,6 +755,18 @@ static void camera_for_size(const rt_scene& s, uint32_t width, uint32_t height, 
     }
 }
 
+// The f64 parity arrays, flattened and uploaded at their first use (the scene's device must be current).
+static void ensure_reference64(rt_scene& s) {
+    if (s.ref64_ready) return;
+    if (!s.ref64_source) throw std::runtime_error("the scene lost the source of its f64 parity arrays");
+    flatten_reference64(s);
+    s.dev.nodes64 = upload(s, s.nodes64);
+    s.dev.prims64 = upload(s, s.prims64);
+    s.ref64_source.reset();
+    s.nodes64 = {}, s.prims64 = {};
+    s.ref64_ready = true;
+}
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_last_error.c_str(); }
@@ -797,14 +809,17 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         validate(*desc);
         auto s = std::make_unique<rt_scene>();
         auto t0 = std::chrono::steady_clock::now();
-        // The device context (0.1-0.2 s in a cold process: HIP runtime, code objects) is NOT created beside the tree
-        // builds any more: with the runtime initialising on one thread while the builds' threads ran, one cold start in
-        // 50-100 ended in a segmentation fault inside scene creation (160 starts without the overlap: none); the
-        // 40 ms the overlap saved are not worth that.  The first HIP call below creates the context.
+        // Every knob of scene creation comes from the environment HERE, on the calling thread, before the first
+        // worker starts: the workers read no environment (host/worker.h).
+        const BuildKnobs knobs = BuildKnobs::from_environment();
+        // The device context (0.1-0.2 s in a cold process: HIP runtime, code objects) is created on the calling
+        // thread, by the first HIP call below, and never beside this library's workers (with the runtime
+        // initialising on a short-lived thread while the builds started and joined some thirty threads, one cold
+        // start in 50-100 died of a SIGSEGV that no handler saw — the runtime's own threads block every signal —
+        // and 0 of 760 have without the overlap).
         {
-            const char* how = getenv("RT_BUILD");
             int build_device = -1;  // -1: the render tree is built on the host
-            if ((desc->use_bvh == 2 || (desc->use_bvh && how && std::string(how) == "device")) && device != RT_DEVICE_NONE) {
+            if ((desc->use_bvh == 2 || (desc->use_bvh && knobs.device_build)) && device != RT_DEVICE_NONE) {
                 if (device >= 0) build_device = device;
                 else HIP_CHECK(hipGetDevice(&build_device));
             }
@@ -815,24 +830,25 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
                 DeviceGuard first_use(build_device);
                 HIP_CHECK(hipFree(nullptr));
             }
-            auto render_job = std::async(std::launch::async, [&, build_device]() {
+            auto render_job = run_async([&, build_device]() {
                 const auto r0 = std::chrono::steady_clock::now();
-                build_render_tree(*desc, *s, build_device);
+                build_render_tree(*desc, *s, build_device, knobs);
                 s->info.render_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
             });
             build_bvh(*desc, s->bvh);
+            reference_tree_info(*s, desc->n_surfaces);
             const auto t1 = std::chrono::steady_clock::now();
             render_job.get();
             const auto t2 = std::chrono::steady_clock::now();
-            // the two flattenings write disjoint members (the render one reads the reference tree's leaf order only)
-            auto flat64 = std::async(std::launch::async, [&]() { flatten_reference64(*desc, *s); });
+            // beside the render flattening: the copy of what the f64 parity arrays will be made of, if ever asked for
+            auto source64 = run_async([&]() { capture_reference64_source(*desc, *s); });
             flatten_render(*desc, *s);
             const auto t3 = std::chrono::steady_clock::now();
-            flat64.get();
-            if (getenv("RT_BUILD_DEBUG")) {
+            source64.get();
+            if (knobs.debug) {
                 auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
                 fprintf(stderr, "scene create: reference-topology tree %.1f ms (render tree beside it: %.1f ms, waited %.1f ms more), "
-                                "flatten render %.1f ms (reference beside it, waited %.1f ms more)\n",
+                                "flatten render %.1f ms (f64 source copy beside it, waited %.1f ms more)\n",
                         ms(t0, t1), s->info.render_build_ms, ms(t1, t2), ms(t2, t3), ms(t3, std::chrono::steady_clock::now()));
             }
         }
@@ -877,8 +893,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         s->dev.materials = upload(*s, s->materials);
         s->dev.mat_kind = upload(*s, s->mat_kind);
         s->dev.slot_surface = upload(*s, s->slot_surface);
-        s->dev.nodes64 = upload(*s, s->nodes64);
-        s->dev.prims64 = upload(*s, s->prims64);
+        s->dev.nodes64 = nullptr, s->dev.prims64 = nullptr;  // on demand: ensure_reference64
         std::vector<DevCounters> zero(1);
         for (rt_scene::Slot& sl : s->slots) {
             sl.d_counters = const_cast<DevCounters*>(upload(*s, zero));
@@ -890,7 +905,12 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cus = (uint32_t)prop.multiProcessorCount;
         // set-up of rt_render_device_noalloc: the static scratch's address on this device (this device is current)
-        HIP_CHECK(persistent_static_scratch(device, &s->static_acc, &s->static_counters));
+        // and the event that orders that entry point's calls on it.  A failed lookup (a device index beyond the
+        // table, say) only disables that entry point — it reports the missing scratch itself.
+        if (persistent_static_scratch(device, &s->static_acc, &s->static_counters, &s->noalloc_done) != hipSuccess) {
+            (void)hipGetLastError();
+            s->static_acc = nullptr, s->static_counters = nullptr, s->noalloc_done = nullptr;
+        }
         *out = s.release();
         return 0;
     } catch (const std::exception& e) {
@@ -1038,9 +1058,20 @@ int rt_render_device_noalloc(rt_scene* scene, const rt_render_params* params, fl
         camera_for_size(*scene, rp.width, rp.height, dev);
         // launch_render_persistent clears the accumulator it needs and the chunk cursor on `stream` before the
         // kernel: the scratch keeps the previous call's contents, nothing else of it is read
+        // Every call on this GPU shares the one scratch array: a call first makes its stream wait for the previous
+        // call's end (an event made at scene creation, one per GPU, so nothing is allocated here) and records its own
+        // end on it.  Calls from ONE host thread — across streams and scenes — therefore serialise instead of racing;
+        // calls from several host threads must still be ordered by the caller.
+        // (Not on a stream under graph capture, where an event from outside the capture may not be waited on: there
+        // the graph's own order is the caller's.)
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream_v, &capture) != hipSuccess) (void)hipGetLastError(), capture = hipStreamCaptureStatusNone;
+        const bool ordered = capture == hipStreamCaptureStatusNone;
+        if (ordered) HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_v, *scene->noalloc_done, 0));
         HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, scene->static_acc, d_rgb_sum,
                                            scene->static_counters, &scene->static_counters->work, false,
                                            (hipStream_t)stream_v));
+        if (ordered) HIP_CHECK(hipEventRecord(*scene->noalloc_done, (hipStream_t)stream_v));
         return 0;
     } catch (const std::exception& e) {
         return set_error(std::string("rt_render_device_noalloc: ") + e.what());
@@ -1080,6 +1111,7 @@ int rt_primary_hits(rt_scene* scene, uint32_t width, uint32_t height, int precis
             throw std::runtime_error("reference-topology BVH of depth " + std::to_string(scene->info.max_depth) +
                                      " exceeds the parity kernel's stack (" + std::to_string(kPrimary64Stack) + " entries)");
         DeviceGuard guard(scene->device);
+        if (precision == 64) ensure_reference64(*scene);
         const size_t n = (size_t)width * height;
         HIP_CHECK(hipMalloc((void**)&d_id, n * sizeof(int32_t)));
         HIP_CHECK(hipMalloc((void**)&d_t, n * sizeof(double)));

@@ -473,12 +473,12 @@ inline unsigned int grid_for(size_t n) { return (unsigned int)((n + 255) / 256);
 
 // bounds6: lo.xyz hi.xyz per primitive, f32, rounded outward by the caller; ids[i] = the surface id of primitive i.
 void build_render_bvh_device(const std::vector<float>& bounds6, const std::vector<int32_t>& surface_ids, uint32_t max_leaf,
-                             Bvh& out) {
+                             const BuildKnobs& knobs, Bvh& out) {
     out = Bvh{};
     const int n = (int)surface_ids.size();
     if (n == 0) return;
-    const bool debug = getenv("RT_BUILD_DEBUG") != nullptr;
-    const int small = getenv("RT_BUILD_SMALL") ? std::min(kSmallMax, std::max(2, atoi(getenv("RT_BUILD_SMALL")))) : kSmallDefault;
+    const bool debug = knobs.debug;  // (the environment is read by the caller's thread, never by a worker: host/worker.h)
+    const int small = knobs.small ? std::min(kSmallMax, std::max(2, knobs.small)) : kSmallDefault;
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();

@@ -15,7 +15,7 @@ size_t persistent_acc_bytes(uint32_t width, uint32_t height);
 // library's static device scratch, and that scratch's addresses on `device`, which must be the current device
 // on the first call for it (render_persistent.hip)
 constexpr uint32_t kNoAllocMaxTiles = 32768;
-hipError_t persistent_static_scratch(int device, float** d_acc, DevCounters** d_counters);
+hipError_t persistent_static_scratch(int device, float** d_acc, DevCounters** d_counters, hipEvent_t** done);
 // tile-planar accumulator -> row-major interleaved framebuffer
 hipError_t launch_resolve(const float* d_acc, uint32_t width, uint32_t height, float* d_rgb_sum, hipStream_t stream);
 // pooled persistent kernel (render_pool.hip): same arguments; false = use launch_render_persistent instead

@@ -554,8 +554,11 @@ static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mutex;
 static void* g_scratch_ptr[kMaxDevices] = {};
+static hipEvent_t g_scratch_done[kMaxDevices] = {};  // end of the last rt_render_device_noalloc call on the device
 
-hipError_t persistent_static_scratch(int device, float** d_acc, DevCounters** d_counters) {
+// Once per device, with that device current (rt_scene_create): the device address of `scratch` and the event that
+// orders the calls which share it.  *done points into a table that lives as long as the library.
+hipError_t persistent_static_scratch(int device, float** d_acc, DevCounters** d_counters, hipEvent_t** done) {
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
@@ -567,10 +570,14 @@ hipError_t persistent_static_scratch(int device, float** d_acc, DevCounters** d_
         e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!ptr) return hipErrorInvalidSymbol;
-        g_scratch_ptr[device] = ptr;
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = ptr, g_scratch_done[device] = ev;
     }
     *d_acc = (float*)g_scratch_ptr[device];
     *d_counters = (DevCounters*)((unsigned char*)g_scratch_ptr[device] + kStaticAccBytes);
+    *done = &g_scratch_done[device];
     return hipSuccess;
 }
 

@@ -108,7 +108,7 @@ struct Builder {
         int32_t l, r;
         if (depth <= kParallelDepth && split >= kParallelMin && n - split >= kParallelMin) {
             Bvh left_tree, right_tree;
-            auto left_job = std::async(std::launch::async, [&]() {
+            auto left_job = run_async([&]() {
                 Builder b(items, &left_tree);
                 b.build(first, split, depth + 1);
             });

@@ -8,6 +8,7 @@
 
 #include "../../../include/rt.h"
 #include "vec3.h"
+#include "worker.h"
 
 namespace rt {
 
@@ -43,9 +44,11 @@ namespace rt {
 // Render-path tree: the f32 kernels are free to use their own topology (only the f64 parity kernel and the
 // equal-t tie ranks need the reference's).  Binned SAH (32 bins, all three axes), scale-invariant cost,
 // leaves of at most `max_leaf` surfaces, built over the surface ids in `ids`.  `order` holds surface ids.
-void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out);
+// `traversal_cost`: SAH cost of a node visit relative to one primitive test (BuildKnobs::traversal_cost).
+void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, double traversal_cost, Bvh& out);
 // The same builder on the GPU (hip/bvh_device.hip), on the current device.  bounds6: lo.xyz hi.xyz per primitive,
 // f32, rounded outward; ids[i]: the surface id of primitive i.  Throws on a HIP error.
-void build_render_bvh_device(const std::vector<float>& bounds6, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out);
+void build_render_bvh_device(const std::vector<float>& bounds6, const std::vector<int32_t>& ids, uint32_t max_leaf,
+                             const BuildKnobs& knobs, Bvh& out);
 
 }  // namespace rt

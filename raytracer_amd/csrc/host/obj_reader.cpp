@@ -8,9 +8,11 @@
 #include <algorithm>
 #include <functional>
 #include <stdexcept>
+#include <future>
 #include <thread>
 
 #include "scene_host.h"
+#include "worker.h"
 
 namespace rt {
 
@@ -169,14 +171,17 @@ void load_obj_first_model(const std::string& path, ObjMesh& out) {
         const size_t e = nl ? (size_t)(nl - data.data()) : data.size();
         size_t b = p;
         while (b < e && (data[b] == ' ' || data[b] == '\t')) ++b;
-        if (b + 1 < e && (data[b + 1] == ' ' || data[b + 1] == '\t')) {
+        // the keyword is the first whitespace-separated token (tobj: split_whitespace), so a bare `g` or `o` line —
+        // `g\r\n` included — is an object/group statement too (its model is then tobj's "unnamed_object")
+        size_t le = e;
+        while (le > b && (data[le - 1] == '\r' || data[le - 1] == ' ' || data[le - 1] == '\t')) --le;
+        if (b < le && (b + 1 == le || data[b + 1] == ' ' || data[b + 1] == '\t')) {
             if (data[b] == 'f') seen_face = true;
             if (data[b] == 'o' || data[b] == 'g') {
                 if (seen_face) break;
-                size_t nb = b + 1, le = e;
-                while (le > nb && (data[le - 1] == '\r' || data[le - 1] == ' ' || data[le - 1] == '\t')) --le;
+                size_t nb = b + 1;
                 while (nb < le && (data[nb] == ' ' || data[nb] == '\t')) ++nb;
-                if (nb < le) name = data.substr(nb, le - nb);
+                name = nb < le ? data.substr(nb, le - nb) : std::string("unnamed_object");
             }
         }
         line_start.push_back(p);
@@ -190,13 +195,14 @@ void load_obj_first_model(const std::string& path, ObjMesh& out) {
     const size_t n_threads = n_lines < 20000 ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<Run> runs(n_threads);
     {
-        std::vector<std::thread> pool;
+        // (futures, not bare threads: a failed thread start or a throwing run unwinds through joins, not std::terminate)
+        std::vector<std::future<void>> pool;
         for (size_t t = 0; t < n_threads; ++t) {
             const size_t first = n_lines * t / n_threads, last = n_lines * (t + 1) / n_threads;
             if (t + 1 == n_threads) parse_run(data, line_start, first, last, runs[t]);
-            else pool.emplace_back(parse_run, std::cref(data), std::cref(line_start), first, last, std::ref(runs[t]));
+            else pool.push_back(run_async([&data, &line_start, first, last, &runs, t]() { parse_run(data, line_start, first, last, runs[t]); }));
         }
-        for (auto& th : pool) th.join();
+        for (auto& job : pool) job.get();
     }
     const Run* first_error = nullptr;
     for (const Run& r : runs)

@@ -13,7 +13,6 @@ namespace rt {
 namespace {
 
 constexpr int kBins = 32;
-static double kTraversalCost = 1.0;  // relative to one primitive test
 constexpr double kIntersectCost = 1.0;
 
 struct Item {
@@ -49,18 +48,19 @@ struct RBuilder {
     std::vector<Item>& items;
     Bvh* out;
     uint32_t max_leaf;
-    RBuilder(std::vector<Item>& it, Bvh* o, uint32_t ml) : items(it), out(o), max_leaf(ml) {}
+    double traversal_cost;  // relative to one primitive test
+    RBuilder(std::vector<Item>& it, Bvh* o, uint32_t ml, double ct) : items(it), out(o), max_leaf(ml), traversal_cost(ct) {}
 
     // both subtrees of the node `self` (already pushed); [first, mid) and [mid, first + n)
     void children(int32_t self, const Aabb& box, size_t first, size_t mid, size_t n, uint32_t depth) {
         int32_t l, r;
         if (depth <= kParallelDepth && mid - first >= kParallelMin && first + n - mid >= kParallelMin) {
             Bvh left_tree, right_tree;
-            auto left_job = std::async(std::launch::async, [&]() {
-                RBuilder b(items, &left_tree, max_leaf);
+            auto left_job = run_async([&]() {
+                RBuilder b(items, &left_tree, max_leaf, traversal_cost);
                 b.build(first, mid - first, depth + 1);
             });
-            RBuilder b(items, &right_tree, max_leaf);
+            RBuilder b(items, &right_tree, max_leaf, traversal_cost);
             b.build(mid, first + n - mid, depth + 1);
             left_job.get();
             l = splice(*out, left_tree);
@@ -141,7 +141,7 @@ struct RBuilder {
             }
         }
         const double parent_area = std::max(area(box), 1e-300);
-        const double split_cost = kTraversalCost + kIntersectCost * best_cost / parent_area;
+        const double split_cost = traversal_cost + kIntersectCost * best_cost / parent_area;
         const double leaf_cost = kIntersectCost * (double)n;
         if (n <= max_leaf && (best_axis < 0 || leaf_cost <= split_cost)) return leaf(first, n, box, depth);
 
@@ -165,11 +165,10 @@ struct RBuilder {
 
 }  // namespace
 
-void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, Bvh& out) {
+void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, double traversal_cost, Bvh& out) {
     out = Bvh{};
-    if (getenv("RT_CT")) kTraversalCost = atof(getenv("RT_CT"));
     std::vector<Item> items(ids.size());
-    RBuilder b(items, &out, std::max(1u, max_leaf));
+    RBuilder b(items, &out, std::max(1u, max_leaf), traversal_cost);
     for (size_t i = 0; i < ids.size(); ++i) {
         // the reference's box is inverted for a negative radius and too small for some quads: real bounds here,
         // padded like the reference pads its (possibly flat) quad boxes

@@ -222,3 +222,219 @@ def uv_checker_expected(direction, w, h, scale=UV_SCALE):
     even = cell[:, :, 1, 1] % 2 == 0
     colour = np.where(even[..., None], np.asarray(UV_ALBEDO), np.asarray(UV_ODD)) * np.asarray(L_SKY)
     return colour, safe
+
+
+# ---------------------------------------------------------------- thin lens: camera.rs:43-87
+# get_ray (camera.rs:76-87): the ray starts at origin - offset, offset = lens_radius * (u_b * rd.x + v_b * rd.y) with
+# rd uniform in the unit disk and lens_radius = aperture / 2 (camera.rs:65), and points at
+# P(u, v) = lower_left + u * horizontal + v * vertical, which lies on the plane at `focus_distance` from the origin
+# along the view axis (camera.rs:62-64).  So:  point(s) = origin + s * (P - origin) - (1 - s) * offset.
+#  * s = 1: every lens sample of a pixel sample passes through the same point of the focus plane;
+#  * at depth z along the axis (s = z / focus) the lens samples fill a disk of radius lens_radius * |1 - z / focus|
+#    around the pinhole's hit point — the circle of confusion.
+# All surfaces here are DiffuseLights (emit on both faces, never scatter: material.rs:66-72, 94) over a black sky, so a
+# sample IS the colour of the quad it hits.
+LENS = dict(frm=(0.0, 0.0, 6.0), to=(0.0, 0.0, 0.0), fov=24.0, focus=4.0)
+BOARD_CELL, BOARD_N = 0.25, 8  # cells of the focus-plane board, which spans [-1, 1]^2 at z = frm.z - focus
+
+
+def lens_camera_text(aperture):
+    g = LENS
+    return camera_text(g["frm"], g["to"], g["fov"], g["focus"]) + f"  aperture: {aperture}\n"
+
+
+def board_colour(i, j):
+    """Emission of cell (i, j): no two neighbours alike, every channel in (0, 1)."""
+    return (0.15 + 0.1 * i, 0.15 + 0.1 * j, 0.1 + 0.8 * ((i + j) % 2))
+
+
+def _light_quad(q, u, v, colour):
+    return (f"    - type: quad\n      position: [{q[0]}, {q[1]}, {q[2]}]\n"
+            f"      sides: [[{u[0]}, {u[1]}, {u[2]}], [{v[0]}, {v[1]}, {v[2]}]]\n"
+            f"      material: {{type: diffuseLight, albedo: [{colour[0]}, {colour[1]}, {colour[2]}]}}\n")
+
+
+def lens_board_yaml(tmp_path, aperture, name="lensboard"):
+    """An 8 x 8 board of emissive cells ON the focus plane: the image does not depend on the aperture."""
+    z = LENS["frm"][2] - LENS["focus"]
+    text = lens_camera_text(aperture) + "scene:\n  background: [0, 0, 0]\n  surfaces:\n"
+    for i in range(BOARD_N):
+        for j in range(BOARD_N):
+            text += _light_quad((-1 + i * BOARD_CELL, -1 + j * BOARD_CELL, z), (BOARD_CELL, 0, 0), (0, BOARD_CELL, 0),
+                                board_colour(i, j))
+    p = tmp_path / f"{name}_{aperture}.yaml"
+    p.write_text(text)
+    return str(p)
+
+
+def lens_board_expected(w, h):
+    """(colour[h, w, 3], safe[h, w]): the cell each pixel's focus-plane point lies in; `safe` = the pixel's whole
+    jitter window lies inside one cell, 0.2 pixels or more from its border."""
+    g = LENS
+    o, d = camera_rays(g["frm"], g["to"], g["fov"], w / h, w, h, focus=g["focus"], sub=3, edges=True)
+    p = o + d  # s = 1: the focus plane
+    ci, cj = np.floor((p[..., 0] + 1) / BOARD_CELL), np.floor((p[..., 1] + 1) / BOARD_CELL)
+    px = 2.0 * g["focus"] * math.tan(math.radians(g["fov"]) / 2.0) / h
+    fx, fy = (p[..., 0] + 1) / BOARD_CELL - ci, (p[..., 1] + 1) / BOARD_CELL - cj
+    m = 0.2 * px / BOARD_CELL
+    inside = (fx > m) & (fx < 1 - m) & (fy > m) & (fy < 1 - m) & (ci >= 0) & (ci < BOARD_N) & (cj >= 0) & (cj < BOARD_N)
+    safe = inside.all(axis=(2, 3)) & (ci.max(axis=(2, 3)) == ci.min(axis=(2, 3))) & (cj.max(axis=(2, 3)) == cj.min(axis=(2, 3)))
+    i, j = ci[:, :, 1, 1].astype(int), cj[:, :, 1, 1].astype(int)
+    colour = np.stack([0.15 + 0.1 * i, 0.15 + 0.1 * j, 0.1 + 0.8 * ((i + j) % 2)], axis=-1)
+    return colour, safe
+
+
+QUADRANT_Z, QUADRANT_X0, QUADRANT_Y0 = -2.0, 0.1, -0.05  # depth 8 = 2 x focus: circle of confusion = lens radius
+QUADRANT_COLOURS = {(0, 0): (0.9, 0.1, 0.1), (1, 0): (0.1, 0.9, 0.1), (0, 1): (0.1, 0.1, 0.9), (1, 1): (0.8, 0.8, 0.2)}
+
+
+def lens_quadrants_yaml(tmp_path, aperture, name="lensquadrants"):
+    """Four large emissive quads that meet in one point, OFF the focus plane: each colour edge blurs by the circle of
+    confusion, a disk of radius aperture / 2 * |1 - depth / focus| around the pinhole's hit point."""
+    text = lens_camera_text(aperture) + "scene:\n  background: [0, 0, 0]\n  surfaces:\n"
+    for (sx, sy), colour in QUADRANT_COLOURS.items():
+        text += _light_quad((QUADRANT_X0, QUADRANT_Y0, QUADRANT_Z), (10.0 if sx else -10.0, 0, 0), (0, 10.0 if sy else -10.0, 0), colour)
+    p = tmp_path / f"{name}_{aperture}.yaml"
+    p.write_text(text)
+    return str(p)
+
+
+def lens_quadrants_expected(w, h, aperture, lens_grid=64):
+    """(mean[h, w, 3], var[h, w, 3]): expectation and variance of ONE sample of each pixel — the colour under
+    pinhole_hit - (1 - depth / focus) * offset.  Exact over the jitter window (the window maps to a rectangle on
+    the quads' plane and the colour edges are axis-parallel: overlaps of intervals), a uniform grid of points over
+    the lens disk."""
+    g = LENS
+    o, d = camera_rays(g["frm"], g["to"], g["fov"], w / h, w, h, focus=g["focus"], sub=2, edges=True)
+    s = (g["frm"][2] - QUADRANT_Z) / g["focus"]
+    pin = o + s * d  # (h, w, 2, 2, 3): the corners of each pixel's jitter window on the plane
+    x_lo, x_hi = pin[..., 0].min(axis=(2, 3)), pin[..., 0].max(axis=(2, 3))
+    y_lo, y_hi = pin[..., 1].min(axis=(2, 3)), pin[..., 1].max(axis=(2, 3))
+    a = (np.arange(lens_grid) + 0.5) / lens_grid * 2 - 1
+    lx, ly = np.meshgrid(a, a)
+    keep = lx * lx + ly * ly < 1
+    # the camera looks down -z with vup = +y: u_b = +x, v_b = +y (camera.rs:57-59)
+    off = 0.5 * aperture * (1 - s) * np.stack([lx[keep], ly[keep]], axis=-1)  # (n_lens, 2)
+    # fraction of the (shifted) window on the high side of each edge, per lens point
+    fx = np.clip((x_hi[..., None] - off[:, 0] - QUADRANT_X0) / (x_hi - x_lo)[..., None], 0.0, 1.0)
+    fy = np.clip((y_hi[..., None] - off[:, 1] - QUADRANT_Y0) / (y_hi - y_lo)[..., None], 0.0, 1.0)
+    mean = np.zeros((h, w, 3))
+    second = np.zeros((h, w, 3))
+    for (qx, qy), colour in QUADRANT_COLOURS.items():
+        frac = ((fx if qx else 1 - fx) * (fy if qy else 1 - fy)).mean(axis=-1)
+        c = np.asarray(colour)
+        mean += frac[..., None] * c
+        second += frac[..., None] * c * c
+    return mean, np.maximum(second - mean * mean, 0.0)
+
+
+# ---------------------------------------------------------------- dielectric: material.rs:140-181
+# A glass PANE is one quad: a single interface.  A camera ray that meets it is reflected with probability
+# R = 1 if ratio * sin(theta) > 1 else schlick(cos(theta), ratio), ratio = 1 / index on the front face (d . n < 0,
+# trace.rs:59-76) and index on the back face (material.rs:142-152), and refracted otherwise, along
+# refract(unit(d), n, ratio) (material.rs:175-181).  The reflected ray leaves into the uniform sky (L, attenuation 1).
+# What the refracted ray meets decides the scene:
+#  * a black Lambertian floor (albedo 0): the path's throughput is 0 from there on  ->  E[sample] = L * R;
+#  * a floor of emissive cells at depth `drop` under the pane  ->  E[sample] = L * R + (1 - R) * E(cell under the
+#    Snell-displaced point), the sky's L where the refracted ray misses the cells.
+GLASS_FRONT = dict(frm=(0.0, 2.0, 4.0), to=(0.0, 0.0, 0.0), fov=40.0, ior=1.5, up=True)
+# seen from its back face the pane refracts only steeper than asin(1 / index) from the normal: look down at it
+GLASS_BACK = dict(frm=(0.0, 3.0, 1.5), to=(0.0, 0.0, 0.0), fov=60.0, ior=1.5, up=False)
+GLASS_DROP, GLASS_CELL = 1.0, 0.5
+GLASS_CELLS_X, GLASS_CELLS_Z = (-3.0, 3.0), (-8.0, 3.0)
+GLASS_PALETTE = ((0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9))
+
+
+def glass_cell_colour(i, k):
+    return GLASS_PALETTE[(i + 2 * k) % 3]
+
+
+def glass_pane_yaml(tmp_path, g, floor, name="glass"):
+    """`floor`: "black" (one Lambertian quad of albedo 0) or "cells" (emissive cells).  g["up"]: the pane's normal
+    u x v (surfaces.rs:313-327) points up, at the camera (front face), or down (the camera sees its back)."""
+    sides = "[[0, 0, 100], [100, 0, 0]]" if g["up"] else "[[100, 0, 0], [0, 0, 100]]"
+    text = (camera_text(g["frm"], g["to"], g["fov"])
+            + f"scene:\n  background: [{L_SKY[0]}, {L_SKY[1]}, {L_SKY[2]}]\n  surfaces:\n"
+            + f"    - type: quad\n      position: [-50, 0, -50]\n      sides: {sides}\n"
+            + f"      material: {{type: dielectric, index: {g['ior']}}}\n")
+    if floor == "black":
+        text += ("    - type: quad\n      position: [-100, -1, -100]\n      sides: [[0, 0, 200], [200, 0, 0]]\n"
+                 "      material: {type: lambertian, albedo: [0, 0, 0]}\n")
+    else:
+        nx = int(round((GLASS_CELLS_X[1] - GLASS_CELLS_X[0]) / GLASS_CELL))
+        nz = int(round((GLASS_CELLS_Z[1] - GLASS_CELLS_Z[0]) / GLASS_CELL))
+        for i in range(nx):
+            for k in range(nz):
+                text += _light_quad((GLASS_CELLS_X[0] + i * GLASS_CELL, -GLASS_DROP, GLASS_CELLS_Z[0] + k * GLASS_CELL),
+                                    (0, 0, GLASS_CELL), (GLASS_CELL, 0, 0), glass_cell_colour(i, k))
+    p = tmp_path / f"{name}_{'front' if g['up'] else 'back'}_{floor}.yaml"
+    p.write_text(text)
+    return str(p)
+
+
+def glass_pane_expected(g, w, h, floor, sub=12):
+    """(mean[h, w, 3], var[h, w, 3], r[h, w], quad_err[h, w, 3]): expectation and variance of one sample per pixel, the
+    mean reflection probability (1 where the pixel looks at the sky: there the sample is L with certainty), and a bound on
+    the error of the sub x sub midpoint quadrature over the jitter window: steps inside a pixel — cell edges under the
+    pane, the critical angle where R jumps from Schlick's value to 1 — cost at most their height per sub-interval (found
+    on a grid that spans the window border to border)."""
+    sky = np.asarray(L_SKY)
+    n = np.array([0.0, 1.0, 0.0])  # the normal against the ray (Hit::new flips it on the back face)
+    ratio = 1.0 / g["ior"] if g["up"] else g["ior"]  # front face iff the geometric normal points up, at the camera
+    nx = int(round((GLASS_CELLS_X[1] - GLASS_CELLS_X[0]) / GLASS_CELL))
+    nz = int(round((GLASS_CELLS_Z[1] - GLASS_CELLS_Z[0]) / GLASS_CELL))
+
+    def moments(o, d):
+        down = d[..., 1] < 0
+        ud = d / np.linalg.norm(d, axis=-1, keepdims=True)
+        cos_t = np.minimum(-(ud @ n), 1.0)
+        sin_t = np.sqrt(np.maximum(1.0 - cos_t * cos_t, 0.0))
+        r0 = ((1.0 - ratio) / (1.0 + ratio)) ** 2
+        refl = np.where(ratio * sin_t > 1.0, 1.0, r0 + (1.0 - r0) * (1.0 - cos_t) ** 5)
+        refl = np.where(down, refl, 1.0)
+        if floor == "black":
+            below = np.zeros(d.shape)
+        else:
+            perp = ratio * (ud + cos_t[..., None] * n)
+            par = -np.sqrt(np.abs(1.0 - (perp * perp).sum(-1)))
+            t_dir = perp + par[..., None] * n
+            t_pane = np.where(down, -o[1] / np.where(down, d[..., 1], -1.0), 0.0)
+            hit = o + t_pane[..., None] * d
+            fl = hit + t_dir * (GLASS_DROP / np.maximum(-t_dir[..., 1], 1e-12))[..., None]
+            i = np.floor((fl[..., 0] - GLASS_CELLS_X[0]) / GLASS_CELL).astype(int)
+            k = np.floor((fl[..., 2] - GLASS_CELLS_Z[0]) / GLASS_CELL).astype(int)
+            on = (i >= 0) & (i < nx) & (k >= 0) & (k < nz)
+            pal = np.asarray(GLASS_PALETTE)[(np.clip(i, 0, nx - 1) + 2 * np.clip(k, 0, nz - 1)) % 3]
+            below = np.where(on[..., None], pal, sky)
+        first = refl[..., None] * sky + (1.0 - refl[..., None]) * below
+        second = refl[..., None] * sky * sky + (1.0 - refl[..., None]) * below * below
+        return first, second, refl
+
+    first, second, refl = moments(*camera_rays(g["frm"], g["to"], g["fov"], w / h, w, h, sub=sub))
+    mean = first.mean(axis=(2, 3))
+    var = np.maximum(second.mean(axis=(2, 3)) - mean * mean, 0.0)
+    across, _, _ = moments(*camera_rays(g["frm"], g["to"], g["fov"], w / h, w, h, sub=sub + 1, edges=True))
+    spread = across.max(axis=(2, 3)) - across.min(axis=(2, 3))
+    return mean, var, refl.mean(axis=(2, 3)), spread / sub
+
+
+def statistically_equal(img, mean, var, n, quad_err=None, k_pixel=5.5, k_image=4.5, floor=2e-3):
+    """img (h, w, 3) = average of n samples per pixel whose one-sample expectation / variance are mean / var;
+    quad_err bounds the error of `mean` itself per pixel (treated as uniform in +-quad_err where pixels are averaged).
+    Per pixel within k_pixel sigma + quad_err + floor (f32, the jitter quadrature of smooth terms); the image's mean
+    and its row and column profiles — each averaging many pixels — within k_image of THEIR sigma.  Returns a message
+    for the first violation, or None."""
+    if quad_err is None:
+        quad_err = np.zeros_like(mean)
+    sigma = np.sqrt(var / n)
+    bad = np.abs(img - mean) > k_pixel * sigma + quad_err + floor
+    if bad.any():
+        at = tuple(np.argwhere(bad)[0])
+        return f"pixel {at}: {img[at]:.5f} vs {mean[at]:.5f} +- {sigma[at]:.5f} (quadrature {quad_err[at]:.5f}); {bad.sum()} such"
+    for axes, what in (((0, 1), "image"), ((0,), "column profile"), ((1,), "row profile")):
+        got, want = img.mean(axis=axes), mean.mean(axis=axes)
+        count = np.prod([img.shape[a] for a in axes])
+        s = np.sqrt(var.sum(axis=axes) / n + (quad_err ** 2).sum(axis=axes) / 3.0) / count
+        if (np.abs(got - want) > k_image * s + 0.25 * floor).any():
+            return f"{what}: off by {np.abs(got - want).max():.5f}, sigma {s.max():.5f}"
+    return None

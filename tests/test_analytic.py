@@ -116,3 +116,75 @@ def test_uv_checker_sphere_pattern(ref, tmp_path, direction):
     assert safe.sum() > 300
     assert np.allclose(img[safe], want[safe], rtol=1e-9), (direction, np.abs(img[safe] - want[safe]).max())
     assert len(np.unique(want[safe][:, 2])) == 2  # both colours are in view
+
+
+# ---- thin lens (camera.rs:43-87): the headline scene lucy.yaml is the one shipped scene with an aperture
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_thin_lens_focus_plane_is_sharp_at_any_aperture(ref, tmp_path, sampler):
+    """Every lens sample of a pixel sample passes through the same point of the focus plane: an emissive board ON
+    that plane renders the same — exactly the cell colour under each pixel — with aperture 0, 0.5 and 1 (lens radius
+    two cells wide)."""
+    w = h = 64
+    sn = 4
+    want, safe = A.lens_board_expected(w, h)
+    assert safe.sum() > 0.5 * w * h and len(np.unique(want[safe].round(3), axis=0)) >= 30
+    for aperture in (0, 0.5, 1.0):
+        img, _ = ref.RefScene.from_yaml(A.lens_board_yaml(tmp_path, aperture), 1.0).render(w, h, sn, threads=8, sampler=sampler)
+        img /= sn * sn
+        assert np.allclose(img[safe], want[safe], rtol=1e-12), (aperture, np.abs(img[safe] - want[safe]).max())
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_thin_lens_circle_of_confusion(ref, tmp_path, sampler):
+    """Off the focus plane a colour edge blurs over the disk of radius aperture / 2 * |1 - depth / focus|."""
+    w = h = 48
+    sn = 24
+    n = sn * sn
+    for aperture in (0.0, 0.5):
+        img, _ = ref.RefScene.from_yaml(A.lens_quadrants_yaml(tmp_path, aperture), 1.0).render(w, h, sn, threads=8, sampler=sampler)
+        mean, var = A.lens_quadrants_expected(w, h, aperture)
+        assert A.statistically_equal(img / n, mean, var, n) is None, aperture
+    # the test has teeth: the blur of aperture 0.5 is not that of 0.25 or 1.0 (aperture / 2 is the lens radius)
+    for wrong in (0.25, 1.0):
+        mean, var = A.lens_quadrants_expected(w, h, wrong)
+        assert A.statistically_equal(img / n, mean, var, n) is not None, wrong
+
+
+# ---- dielectric (material.rs:140-181): Schlick's split, the front_face choice of ratio, refract's direction
+@pytest.mark.parametrize("sampler", [0, 1])
+@pytest.mark.parametrize("side", ["front", "back"])
+def test_glass_pane_reflects_with_schlick_probability(ref, tmp_path, side, sampler):
+    """A one-quad pane over a black floor under the sky: E[sample] = L * R(cos theta), R = Schlick at ratio 1 / index
+    on the front face, index on the back face, and 1 beyond the critical angle."""
+    g = A.GLASS_FRONT if side == "front" else A.GLASS_BACK
+    w = h = 40
+    sn = 24
+    n = sn * sn
+    img, _ = ref.RefScene.from_yaml(A.glass_pane_yaml(tmp_path, g, "black"), 1.0).render(w, h, sn, threads=8, sampler=sampler)
+    mean, var, r, qe = A.glass_pane_expected(g, w, h, "black")
+    assert r.min() < 0.06 and (r[r < 1] > 0.3).any()  # from near-normal to grazing incidence
+    if side == "back":
+        assert ((r == 1) & (mean[..., 0] > 0)).any()   # total internal reflection is in view
+    assert A.statistically_equal(img / n, mean, var, n, qe) is None
+    # teeth: the other face's ratio does not fit
+    other = dict(g, up=not g["up"])
+    mean, var, _, qe = A.glass_pane_expected(other, w, h, "black")
+    assert A.statistically_equal(img / n, mean, var, n, qe) is not None
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+@pytest.mark.parametrize("side", ["front", "back"])
+def test_glass_pane_refracts_by_snell(ref, tmp_path, side, sampler):
+    """Emissive cells one unit under the pane: the colour mixed in with probability 1 - R is the cell under the
+    Snell-displaced point (refract, material.rs:175-181)."""
+    g = A.GLASS_FRONT if side == "front" else A.GLASS_BACK
+    w = h = 40
+    sn = 24
+    n = sn * sn
+    img, _ = ref.RefScene.from_yaml(A.glass_pane_yaml(tmp_path, g, "cells"), 1.0).render(w, h, sn, threads=8, sampler=sampler)
+    mean, var, _, qe = A.glass_pane_expected(g, w, h, "cells")
+    assert A.statistically_equal(img / n, mean, var, n, qe) is None
+    # teeth: a ray that went straight on (ratio 1), or bent the other way, would light other cells
+    for wrong in (1.0, 1.0 / g["ior"]):
+        mean, var, _, qe = A.glass_pane_expected(dict(g, ior=wrong), w, h, "cells")
+        assert A.statistically_equal(img / n, mean, var, n, qe) is not None, wrong

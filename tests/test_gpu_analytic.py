@@ -146,3 +146,67 @@ def test_uv_checker_sphere_pattern(ra, tmp_path, direction):
         colour = np.array(A.UV_ALBEDO if even else A.UV_ODD) * SKY
         assert np.allclose(c, colour, rtol=F32[0]), (direction, c)
     scene.close()
+
+
+# ---- thin lens (camera.rs:43-87; the headline scene lucy.yaml is the one shipped scene with an aperture)
+def test_thin_lens_focus_plane_is_sharp_at_any_aperture(ra, tmp_path):
+    """An emissive board ON the focus plane renders exactly the cell colour under each pixel whatever the aperture:
+    every lens sample of a pixel sample passes through the same point of that plane."""
+    w = h = 64
+    sn = 8
+    want, safe = A.lens_board_expected(w, h)
+    assert safe.sum() > 0.5 * w * h
+    for aperture in (0, 0.5, 1.0):
+        scene = ra.Scene(ra.load_scene(A.lens_board_yaml(tmp_path, aperture), 1.0), 0)
+        for kernel in (0, 1, 2):
+            for sampler in (0, 1):
+                img, _ = scene.render(w, h, sn, kernel=kernel, sampler=sampler)
+                img = img.astype(np.float64) / (sn * sn)
+                assert np.allclose(img[safe], want[safe], rtol=F32[kernel]), (aperture, kernel, sampler,
+                                                                               np.abs(img[safe] - want[safe]).max())
+        scene.close()
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_thin_lens_circle_of_confusion(ra, tmp_path, sampler):
+    """Off the focus plane the colour edges blur over the disk of radius aperture / 2 * |1 - depth / focus|."""
+    w = h = 48
+    sn = 64
+    n = sn * sn
+    for aperture in (0.0, 0.5):
+        scene = ra.Scene(ra.load_scene(A.lens_quadrants_yaml(tmp_path, aperture), 1.0), 0)
+        mean, var = A.lens_quadrants_expected(w, h, aperture)
+        for kernel in (0, 1, 2):
+            img, _ = scene.render(w, h, sn, kernel=kernel, sampler=sampler)
+            img = img.astype(np.float64) / n
+            assert A.statistically_equal(img, mean, var, n) is None, (aperture, kernel)
+        scene.close()
+    for wrong in (0.4, 0.6):  # teeth at 4096 spp: a lens radius 20 % off does not fit
+        mean, var = A.lens_quadrants_expected(w, h, wrong)
+        assert A.statistically_equal(img, mean, var, n) is not None, wrong
+
+
+# ---- dielectric (material.rs:140-181): Schlick's split, the front_face choice of ratio, refract's direction
+@pytest.mark.parametrize("sampler", [0, 1])
+@pytest.mark.parametrize("side", ["front", "back"])
+@pytest.mark.parametrize("floor", ["black", "cells"])
+def test_glass_pane(ra, tmp_path, floor, side, sampler):
+    """black floor: E[sample] = L * R(cos theta) — Schlick at ratio 1 / index on the front face, index on the back,
+    1 beyond the critical angle; emissive cells under the pane: the colour mixed in with probability 1 - R is the
+    cell under the Snell-displaced point.  The cells (264 quads) live in the render tree, the pane stays loose."""
+    g = A.GLASS_FRONT if side == "front" else A.GLASS_BACK
+    w = h = 40
+    sn = 64
+    n = sn * sn
+    scene = ra.Scene(ra.load_scene(A.glass_pane_yaml(tmp_path, g, floor), 1.0), 0)
+    if floor == "cells":
+        assert scene.info().render_nodes > 100 and scene.info().n_loose >= 1
+    mean, var, _, qe = A.glass_pane_expected(g, w, h, floor)
+    for kernel in (0, 1, 2):
+        img, _ = scene.render(w, h, sn, kernel=kernel, sampler=sampler)
+        img = img.astype(np.float64) / n
+        assert A.statistically_equal(img, mean, var, n, qe) is None, kernel
+    scene.close()
+    wrong = dict(g, up=not g["up"]) if floor == "black" else dict(g, ior=1.0)
+    mean, var, _, qe = A.glass_pane_expected(wrong, w, h, floor)
+    assert A.statistically_equal(img, mean, var, n, qe) is not None

@@ -178,6 +178,24 @@ def test_obj_parsing(ra, tmp_path):
         ra.load_scene(_write(tmp_path, text.replace("m.obj", "quad.obj")), 1.0)
 
 
+def test_obj_bare_group_line_ends_the_first_model(ra, tmp_path):
+    """tobj finds the keyword with split_whitespace: a bare `g` (or `o`) line — `g\\r\\n` in a CRLF file included — is
+    an object/group statement, so after a face it ends the first model (load.rs:225-229 uses the first model only).
+    Product loader and the independent loader agree, and neither merges the second model's faces in."""
+    crlf = "v 0 0 0\r\nv 1 0 0\r\nv 0 1 0\r\nf 1 2 3\r\ng\r\nv 5 5 5\r\nv 6 5 5\r\nv 5 6 5\r\nf 4 5 6\r\n"
+    (tmp_path / "crlf.obj").write_bytes(crlf.encode())
+    (tmp_path / "tabs.obj").write_text("\tv 0 0 0\nv\t1 0 0\nv 0 1 0\nf 1 2 3\n  o  \nv 5 5 5\nf 2 3 4\n")
+    text = CAM + ("scene:\n  background: [0,0,0]\n  surfaces:\n    - type: mesh\n      path: crlf.obj\n"
+                  "      material: {type: lambertian, albedo: [1,1,1]}\n")
+    for name in ("crlf.obj", "tabs.obj"):
+        path = _write(tmp_path, text.replace("crlf.obj", name))
+        d = ra.load_scene(path, 1.0)
+        f = loader_ref.load_scene(path, 1.0)
+        assert len(d.triangles) == 1 and len(f.triangles) == 1, name
+        assert np.array_equal(d.triangles["v"].reshape(-1, 9), f.triangles[:, :9])
+        assert np.abs(d.triangles["v"]).max() <= 0.5  # re-centred on the first model's own box, not the merged one
+
+
 def test_host_only_scene_refuses_to_render(ra):
     s = ra.Scene(ra.load_scene(scene_path("quads"), 1.5), ra.RT_DEVICE_NONE)
     with pytest.raises(ra.api.RtError, match="host-only"):
