@@ -34,6 +34,7 @@ struct Opt {
     int sampler = RT_SAMPLER_DIRECT;
     bool reduce_rccl = true;    // --gpus N: sum the per-GPU framebuffers with one RCCL reduce (else over PCIe on the host)
     double progressive = -1.0;  // >= 0: write the running image every so many seconds
+    bool keep_partials = false;  // with --progressive: every partial image is also kept, as OUTPUT.partial<k>.png
 };
 
 [[noreturn]] void usage_error(const std::string& m) {
@@ -63,6 +64,7 @@ void help() {
         "      --reduce <rccl|host>           How the GPUs' framebuffers are summed: one RCCL reduce over xGMI\n"
         "                                     [default], or copies over PCIe added on the host\n"
         "      --progressive <SECS>           Write the image so far to --output every SECS seconds while rendering\n"
+        "      --keep-partials                With --progressive: also keep every partial image, as OUTPUT.partial<k>.png\n"
         "      --kernel <persistent|wavefront|pool>\n"
         "      --sampler <direct|reference>   Unit-sphere/disk sampling: loop-free maps or the reference's rejection loops\n"
         "      --dump-primary <FILE>          Write the f64 primary-hit AOV (int32 ids, then f64 t) and exit\n"
@@ -117,6 +119,8 @@ Opt parse(int argc, char** argv) {
             if (v == "rccl") o.reduce_rccl = true;
             else if (v == "host") o.reduce_rccl = false;
             else usage_error("invalid value '" + v + "' for '--reduce'");
+        } else if (key == "--keep-partials") {
+            o.keep_partials = true;
         } else if (key == "--progressive") {
             std::string v = need(i, "--progressive");
             char* end = nullptr;
@@ -204,7 +208,23 @@ int main(int argc, char** argv) {
     const double total_samples = (double)width * (double)height * (double)sn * (double)sn;
     const uint32_t n_strata = sn * sn;
     const bool batched = o.progressive >= 0.0 || (!o.no_progress && total_samples > 8e9);
-    const uint32_t batches = batched ? std::min<uint32_t>(32u, std::max(1u, n_strata / (uint32_t)o.gpus)) : 1u;
+    // Batch b renders the strata k = b (mod step), step = batches x GPUs, and stratum k sits at (k / sn, k % sn) of
+    // the pixel's sn x sn grid (main.rs:165-171): a step that shares a factor with sn confines a batch to a few
+    // columns of that grid — with sn = 32 and 32 batches to ONE column, a strip a 32nd of the pixel high, and the
+    // partial images (--progressive) would be estimates of a shifted image.  Up to 32 batches, then: the count whose
+    // step has the smallest common factor with sn (1 where there is one), not congruent to 0 or +-1 modulo sn (the
+    // grid's rows and diagonals), the largest such — the batch's strata then form a lattice spread over the pixel.
+    uint32_t batches = 1u;
+    if (batched) {
+        const uint32_t most = std::min<uint32_t>(32u, std::max(1u, n_strata / (uint32_t)o.gpus));
+        auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b, b = t; } return a; };
+        uint32_t best_score = 0xffffffffu;
+        for (uint32_t c = most; c >= 1u && c + 8u > most; --c) {
+            const uint32_t step = c * (uint32_t)o.gpus, r = step % sn;
+            const uint32_t score = 4u * gcd(step, sn) + ((sn > 2u && (r == 0u || r == 1u || r == sn - 1u)) ? 2u : 0u);
+            if (score < best_score) best_score = score, batches = c;
+        }
+    }
     const size_t n_values = 3 * width * height;
     std::vector<float> sum(n_values, 0.f), part(n_values);
     // every GPU renders its strata of the batch into a framebuffer in its own memory
@@ -271,6 +291,9 @@ int main(int argc, char** argv) {
             if (rt_write_png(tmp.c_str(), rgb.data(), (uint32_t)width, (uint32_t)height) || std::rename(tmp.c_str(), o.output.c_str()))
                 return die("could not write image");
             ++partial_images;
+            if (o.keep_partials &&
+                rt_write_png((o.output + ".partial" + std::to_string(partial_images) + ".png").c_str(), rgb.data(), (uint32_t)width, (uint32_t)height))
+                return die("could not write image");
         }
         if (!o.no_progress && batches > 1 && b + 1 < batches && std::chrono::duration<double>(now - last_report).count() >= 1.0) {
             last_report = now;

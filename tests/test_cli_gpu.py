@@ -26,7 +26,7 @@ def test_progressive_writes_partial_images_and_the_same_final_image(tmp_path):
     r = subprocess.run(args + ["--progressive", "0", "-o", str(a)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     m = re.search(r"wrote (\d+) partial images? to", r.stderr)
-    assert m and int(m.group(1)) >= 8, r.stderr          # 32 batches of 2 strata: an image after each but the last
+    assert m and int(m.group(1)) >= 8, r.stderr          # ~30 batches of 2 strata: an image after each but the last
     assert "Done in" in r.stderr and not (tmp_path / "progressive.png.part").exists()
     r = subprocess.run(args + ["-o", str(b)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
@@ -37,14 +37,34 @@ def test_progressive_writes_partial_images_and_the_same_final_image(tmp_path):
 
 
 def test_progressive_partial_image_is_a_coarser_estimate_of_the_final_one(tmp_path):
-    """A long enough interval that only the first partial image is written: it must already look like the final
-    image (every pixel's strata subset is spread over the pixel), just noisier."""
+    """The partial images themselves (--keep-partials keeps every one beside the output): 1024 spp in N ~ 30 batches, so
+    partial k is the image at 1024 k / N spp.  Every batch's strata are a lattice spread over the pixel's 32 x 32 grid
+    (the step between them is coprime to 32), so the first partial already is the final image, only noisier, and the
+    partials close in on it: the RMS distance to the final image falls like sqrt(1/k - 1/N).  (This test, once it
+    read the partials, found the batches confined to one column of the grid — a strip a 32nd of the pixel high.)"""
     out = tmp_path / "p.png"
-    args = [CLI, "--scene", scene_path("quads"), "--width", "120", "--height", "80", "-n", "1024", "--no-progress", "-o", str(out)]
-    r = subprocess.run(args + ["--progressive", "0"], capture_output=True, text=True, timeout=120)
+    args = [CLI, "--scene", scene_path("teapot"), "--width", "120", "--height", "80", "-n", "1024", "--seed", "7", "--no-progress",
+            "-o", str(out)]
+    r = subprocess.run(args + ["--progressive", "0", "--keep-partials"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
+    m = re.search(r"wrote (\d+) partial images to", r.stderr)
+    assert m and 24 <= int(m.group(1)) <= 31, r.stderr
+    last = int(m.group(1))
     final = _png(out)
     assert final.std() > 5  # not a blank frame
+    dist = {}
+    for k in (1, 4, 16, last):
+        part = _png(f"{out}.partial{k}.png")
+        assert part.shape == final.shape == (80, 120, 3)
+        dist[k] = np.sqrt(np.mean((part - final).astype(np.float64) ** 2))  # RMS difference in 8-bit steps
+    print("\nRMS distance of partial k to the final image, 8-bit steps:", {k: round(v, 2) for k, v in dist.items()})
+    model = {k: np.sqrt(1.0 / k - 1.0 / (last + 1)) for k in dist}
+    # measured: 4.30, 2.07, 0.84, 0.29 steps for k = 1, 4, 16, 28 of 29 (with the one-column batches: 10.5, 8.8, 5.1)
+    for k in (4, 16):  # the fall follows the model within a factor 1.4 either way
+        assert 1 / 1.4 < (dist[k] / dist[1]) / (model[k] / model[1]) < 1.4, (dist, model)
+    assert 1.0 < dist[1] < 8.0 and dist[last] < 0.6, dist  # the last partial: the 8-bit rounding's own 0.29 and little more
+    # and the mean brightness is right from the first partial on (normalised by the samples so far)
+    assert abs(_png(f"{out}.partial1.png").mean() - final.mean()) < 0.01 * final.mean() + 0.5
 
 
 def test_cli_gpus_1_with_rccl_reduce_flag_is_accepted(tmp_path):

@@ -8,7 +8,7 @@ import pytest
 
 import synth
 from conftest import scene_path
-from test_gpu_parity import _same_image
+from test_gpu_parity import F32_BUDGET, _check_image, _same_image, classify_f32, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,51 @@ def test_device_built_tree_finds_the_same_hits(ra, name):
         assert st_h.samples == st_d.samples
         assert _same_image(img_h, img_d, 16), (name, kernel)
     host.close(), dev.close()
+
+
+TREE_SCENES = ["cornell", "cornell_lucy", "teapot", "lucy", "dual"]  # the golden scenes that have a render tree
+
+
+@pytest.fixture(scope="module")
+def device_built(ra):
+    cache = {}
+
+    def get(name, aspect):
+        key = (name, round(aspect, 6))
+        if key not in cache:
+            cache[key] = ra.Scene(ra.load_scene(scene_path(name), aspect, use_bvh="device"), 0)
+            assert cache[key].info().device_build == 1
+        return cache[key]
+
+    yield get
+    for s in cache.values():
+        s.close()
+
+
+@pytest.mark.parametrize("name", TREE_SCENES)
+def test_device_built_tree_primary_hits_vs_oracle_golden(device_built, name):
+    """The device-built tree against the ORACLE's golden vectors directly (not against the host-built tree): the f32
+    closest hits within the same budget test_gpu_parity.py holds the host-built tree to."""
+    g = golden(name)
+    h, w = g["prim_id"].shape
+    ids, t = device_built(name, w / h).primary_hits(w, h, precision=32)
+    swaps, flips, n_rel, max_rel = classify_f32(ids, t, g["prim_id"], g["t"])
+    b_swaps, b_flips, b_rel = F32_BUDGET["golden"][name]
+    assert swaps <= b_swaps and flips <= b_flips and n_rel <= b_rel and max_rel <= 2e-4, (swaps, flips, n_rel, max_rel)
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("name", TREE_SCENES)
+def test_device_built_tree_image_matches_oracle_golden(device_built, name, kernel, sampler):
+    """test_image_matches_golden with the render tree built on the GPU: the oracle's image, same bars."""
+    g = golden(name)
+    want = g["image_sum"] if sampler == 0 else g["image_sum_direct"]
+    ih, iw, _ = want.shape
+    img, st = device_built(name, iw / ih).render(iw, ih, 4, max_depth=40, seed=1, kernel=kernel, collect_stats=True,
+                                                 sampler=sampler)
+    _check_image(img, want, 16, name)
+    assert st.samples == iw * ih * 16 and 0 < st.segments <= 1.02 * int(g["segments"])
 
 
 def test_device_build_of_synthetic_scenes(ra, tmp_path):
