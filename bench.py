@@ -190,26 +190,34 @@ def host_cpus():
     return use, allowed, os.cpu_count() or allowed, model, why
 
 
-def cpu_baseline(scene_file: str, width: int, height: int, seconds: float, sampler: int):
+def cpu_baseline(scene_file: str, width: int, height: int, seconds: float):
     """The oracle (the f64 CPU restatement of the reference's render loop, Q1 re-trace cost included) timed on
-    this box's host CPUs on a bounded sample of the same workload: same scene, resolution and sampler, at the
-    spp that a short calibration run says takes about `seconds` (>= 30 s of CPU work)."""
+    this box's host CPUs on a bounded sample of the same workload: same scene and resolution, at the spp that a
+    short calibration run says takes about `seconds` (>= 30 s of CPU work).  Always with the REFERENCE
+    sampler — the rejection loops of util.rs:15-35 are what the reference's CPU renderer runs — whatever sampler the
+    GPU headline uses; the direct maps' CPU figure, on a quarter of the sample, is reported beside it."""
     from oracle import ref
 
     threads, allowed, total, model, why = host_cpus()
     o = ref.RefScene.from_yaml(scene_file, width / height)
-    t0 = time.perf_counter()
-    o.render(width, height, 2, max_depth=40, seed=1, threads=threads, sampler=sampler)
-    per_spp = (time.perf_counter() - t0) / 4.0
+
+    def timed(sn, sampler):
+        t0 = time.perf_counter()
+        o.render(width, height, sn, max_depth=40, seed=1, threads=threads, sampler=sampler)
+        return time.perf_counter() - t0
+
+    per_spp = timed(2, 0) / 4.0
     sn = max(2, min(64, int(round((seconds / per_spp) ** 0.5))))
-    t0 = time.perf_counter()
-    o.render(width, height, sn, max_depth=40, seed=1, threads=threads, sampler=sampler)
-    dt = time.perf_counter() - t0
+    dt = timed(sn, 0)
     n = width * height * sn * sn
+    sn_d = max(2, sn // 2)
+    dt_d = timed(sn_d, 1)
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "cores_allowed": allowed,
             "cores_total": total, "cores_bound_by": why, "cpu_model": model, "kind": "port",
             "sample": f"{os.path.basename(scene_file)} {width}x{height} at {sn * sn} spp ({n} samples, {dt:.1f} s of "
-                      f"{threads} threads), {'direct' if sampler else 'reference'} sampler"}
+                      f"{threads} threads), reference sampler (the rejection loops of util.rs:15-35)",
+            "direct_sampler": {"value": round(width * height * sn_d * sn_d / dt_d / 1e6, 4), "unit": "Msamples/s",
+                               "sample": f"{sn_d * sn_d} spp, {dt_d:.1f} s"}}
 
 
 def main() -> None:
@@ -236,13 +244,17 @@ def main() -> None:
 
     import raytracer_amd as ra
 
-    if os.environ.get("RT_BENCH_HANG_DUMP"):  # debugging aid: where is every thread after N seconds? (then exit)
-        import faulthandler
-
-        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_HANG_DUMP"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Where is every thread after N seconds? (then exit non-zero).  Armed by default with several ranks, so that a
+    # collective that never completes (a first RCCL run on new hardware) ends with stacks on stderr instead of being
+    # killed at the caller's limit; RT_BENCH_HANG_DUMP=SECONDS sets it for any run, 0 disarms.
+    hang_after = float(os.environ.get("RT_BENCH_HANG_DUMP", "600" if world > 1 else "0"))
+    if hang_after > 0:
+        import faulthandler
+
+        faulthandler.dump_traceback_later(hang_after, exit=True)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -258,12 +270,15 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
+        limit = datetime.timedelta(seconds=float(os.environ.get("RT_BENCH_DIST_TIMEOUT", "180")))
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
             # the reduce's blocks queue behind CU-filling render launches: let them go first when slots free up
             os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
 
     scene_file = os.path.join(ROOT, "scenes", f"{args.scene}.yaml")
     w, h = args.width, args.height
@@ -363,6 +378,7 @@ def main() -> None:
 
     samples_per_step = w * h * sn * sn
     value = samples_per_step * args.steps / elapsed / 1e6
+    png_image = rgb8.cpu().numpy() if (args.png and rank == 0) else None  # the headline's last frame, not a later leg's
 
     # The same steps with the other sampler (outside `value`'s timed region): the headline runs the direct maps,
     # the reference's own rejection loops are reported beside it.
@@ -380,6 +396,40 @@ def main() -> None:
     sampler = main_sampler
     kernel_ms = kernel_ms[:args.steps]
     kernel_events.clear()
+
+    # With several ranks `value` is pipelined throughput (three frames in flight).  What one frame takes with nothing
+    # else in flight — render this rank's slice, sum-reduce, tonemap on rank 0, awaited; the max over ranks of the
+    # best of three — and what the SAME frame takes on one GPU alone (every rank renders all strata, no reduce; rank
+    # 0's tonemap included), timed in this process, give the scaling the line reports beside it.
+    frame_latency_s = full_frame_one_gpu_s = None
+    if world > 1:
+        def awaited(fn):
+            best = float("inf")
+            for _ in range(3):
+                fence()
+                t = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(dev)
+                best = min(best, time.perf_counter() - t)
+            return max_over_ranks(best)
+
+        def one_frame():
+            with torch.cuda.stream(streams[0]):
+                render(fbs[0], 0)
+                if rehearsal:
+                    host_reduce(fbs[0], 0)
+                else:
+                    dist.reduce(fbs[0], dst=0, op=dist.ReduceOp.SUM)
+                tonemap(fbs[0], 0)
+
+        def full_frame():
+            scene.render_device(fbs[0].data_ptr(), w, h, sn, max_depth=40, seed=args.seed, kernel=kernel,
+                                stream=streams[0].cuda_stream, sampler=sampler, want_stats=False)
+            tonemap(fbs[0], 0)
+
+        frame_latency_s = awaited(one_frame)
+        full_frame_one_gpu_s = awaited(full_frame)
+        kernel_events.clear()
 
     # Algorithmic work per sample from the counting build of the same kernel, outside the timed region,
     # at reduced spp (per-sample counts do not depend on spp).
@@ -411,6 +461,13 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": f"the reference's own scene file scenes/{args.scene}.yaml + its OBJ mesh (not synthetic)",
             "config": {"workload": workload, "seconds_per_frame": round(elapsed / args.steps, 4),
+                       **({"timing": "pipelined throughput: 3 frames in flight on 3 streams (seconds_per_frame = elapsed / steps)",
+                           "frames_in_flight": 3,
+                           "frame_latency_s": round(frame_latency_s, 5),
+                           "full_frame_one_gpu_s": round(full_frame_one_gpu_s, 5),
+                           "scaling_efficiency_vs_n1": round(full_frame_one_gpu_s / (world * elapsed / args.steps), 4),
+                           "latency_efficiency_vs_n1": round(full_frame_one_gpu_s / (world * frame_latency_s), 4)}
+                          if world > 1 else {"timing": "one frame at a time, awaited"}),
                        "parallelism": (f"REHEARSAL: {world} ranks sharing one GPU, gloo" if rehearsal else
                                        f"strata-sharded x{world}, 1 RCCL sum-reduce/frame") if world > 1 else "1 GPU",
                        "scene_surfaces": int(info.n_surfaces), "render_bvh_nodes": int(info.render_nodes),
@@ -435,9 +492,9 @@ def main() -> None:
                                  "unit": "GB/s", "frac": round(hbm_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS, 6)}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene_file, w, h, args.cpu_seconds, 1 if main_sampler == ra.RT_SAMPLER_DIRECT else 0)
-        if args.png:
-            ra.write_png(args.png, rgb8.cpu().numpy())
+            line["cpu_baseline"] = cpu_baseline(scene_file, w, h, args.cpu_seconds)
+        if png_image is not None:
+            ra.write_png(args.png, png_image)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

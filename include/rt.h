@@ -242,8 +242,10 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
  * rt_scene_create.  Limits: RT_KERNEL_PERSISTENT only, collect_stats == 0, frames of at most 32 768 8x8 tiles
  * (ceil(width/8) * ceil(height/8); 1920x1080 is 32 400) - anything larger is rejected with an error, as is a
  * scene created with RT_DEVICE_NONE.  Enqueues on `stream` and returns; same output as rt_render_device.  Every
- * call on a GPU shares that GPU's one scratch array: calls that overlap on one GPU (two streams, two scenes, two
- * threads) race - order them on one stream or with events. */
+ * call on a GPU shares that GPU's one scratch array.  Calls made by ONE host thread are ordered by the library,
+ * whatever their streams and scenes: an event per GPU, created at rt_scene_create, is waited on by each call's
+ * stream and recorded at the call's end (no allocation; skipped on a stream under graph capture, where the graph's
+ * own order is the caller's).  Calls made by several host threads at once still race: order those yourself. */
 int rt_render_device_noalloc(rt_scene* scene, const rt_render_params* params, float* d_rgb_sum, void* stream);
 
 /* Same, into HOST memory (synchronous; allocates and frees a device framebuffer). */

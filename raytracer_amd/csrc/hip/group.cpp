@@ -92,19 +92,33 @@ int rt_group_create(const int* devices, int n, rt_group** out) {
 int rt_group_reduce_sum(rt_group* g, float* const* d_bufs, size_t count, int root, void* const* streams) {
     if (!g || !d_bufs || root < 0 || (size_t)root >= g->devices.size())
         return rt_set_error_message("rt_group_reduce_sum: bad argument");
+    if (count == 0) return rt_set_error_message("rt_group_reduce_sum: count must be positive");
+    for (size_t i = 0; i < g->devices.size(); ++i)
+        if (!d_bufs[i]) return rt_set_error_message("rt_group_reduce_sum: null buffer for member " + std::to_string(i));
     try {
         const Rccl& r = rccl();
-        int prev = 0;
-        (void)hipGetDevice(&prev);
+        // Whatever way this call ends, the RCCL group it opened is closed again (a group left open would swallow
+        // this thread's next collective) and the caller's device is current again.
+        struct Scope {
+            const Rccl& r;
+            int prev = -1;
+            bool open = false;
+            explicit Scope(const Rccl& rc) : r(rc) { (void)hipGetDevice(&prev); }
+            ~Scope() {
+                if (open) (void)r.GroupEnd();
+                if (prev >= 0) (void)hipSetDevice(prev);
+            }
+        } scope(r);
         check(r.GroupStart(), "ncclGroupStart");
+        scope.open = true;
         for (size_t i = 0; i < g->devices.size(); ++i) {
             if (hipSetDevice(g->devices[i]) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
             check(r.Reduce(d_bufs[i], d_bufs[i], count, ncclFloat, ncclSum, root, g->comms[i],
                            streams ? (hipStream_t)streams[i] : nullptr),
                   "ncclReduce");
         }
+        scope.open = false;  // closed here, with its result checked
         check(r.GroupEnd(), "ncclGroupEnd");
-        (void)hipSetDevice(prev);
         return 0;
     } catch (const std::exception& e) {
         return rt_set_error_message(std::string("rt_group_reduce_sum: ") + e.what());

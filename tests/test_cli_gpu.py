@@ -91,6 +91,13 @@ def test_group_reduce_sum_one_member_clique(ra):
     torch.cuda.synchronize()
     assert torch.equal(x, want)
     assert lib.rt_group_reduce_sum(g, bufs, x.numel(), 3, None) != 0  # a root outside the clique is refused
+    # refused before any RCCL call: a null member buffer, an empty reduce — and the clique still works afterwards
+    assert lib.rt_group_reduce_sum(g, (C.c_void_p * 1)(None), x.numel(), 0, None) != 0
+    assert b"null buffer" in lib.rt_last_error()
+    assert lib.rt_group_reduce_sum(g, bufs, 0, 0, None) != 0
+    ra.api._check(lib.rt_group_reduce_sum(g, bufs, x.numel(), 0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
     lib.rt_group_destroy(g)
 
 
@@ -121,6 +128,13 @@ def test_bench_two_rank_flow_rehearsed_on_one_gpu(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and "REHEARSAL" in line["config"]["parallelism"]
     assert "cpu_baseline" not in line and line["roofline"]["traffic"] is None
+    # several ranks: the line says that its rate is pipelined and carries one frame's awaited latency and the same
+    # frame on one GPU alone beside it (the scaling figures mean nothing here: the ranks share the card)
+    cfg = line["config"]
+    assert cfg["frames_in_flight"] == 3 and "pipelined" in cfg["timing"]
+    assert cfg["frame_latency_s"] > 0 and cfg["full_frame_one_gpu_s"] > 0
+    assert cfg["frame_latency_s"] >= 0.5 * cfg["seconds_per_frame"]
+    assert 0 < cfg["scaling_efficiency_vs_n1"] and 0 < cfg["latency_efficiency_vs_n1"]
     pa, pb = _png(one), _png(two)
     assert pa.shape == pb.shape == (180, 320, 3)
     assert np.abs(pa - pb).max() <= 1 and (pa != pb).mean() <= 0.01  # same sample set, summed in another order

@@ -103,6 +103,23 @@ def test_media_examples_structure(ra):
     assert np.all(d.spheres["radius"][-1000:] == 10) and np.all(np.abs(cluster.mean(0) - [-100 + 82.5, 270 + 82.5, 395 + 82.5]) < 12)
 
 
+def test_a_fifth_medium_is_refused_with_a_message(ra):
+    """The kernels hold at most four constant media (kMaxMedia, device_scene.h; the eight examples need two): a scene
+    description with a fifth is refused at rt_scene_create — host-only, no device needed — with a message, not
+    rendered wrongly.  Four are accepted."""
+    d = ra.example_scene("cornell-smoke", 1.0)
+    media = np.concatenate([d.media, d.media, d.media[:1]])  # 5 media over the same two boundaries
+    surfaces = np.concatenate([d.surfaces, np.array([(3, 2), (3, 3), (3, 4)], dtype=d.surfaces.dtype)])
+
+    def make(n_media, n_surf):
+        return ra.SceneDesc.from_arrays(d.materials, d.spheres, d.triangles, d.quads, surfaces[:n_surf], d.background,
+                                        d.camera, media=media[:n_media])
+
+    ra.Scene(make(4, len(d.surfaces) + 2), ra.RT_DEVICE_NONE).close()
+    with pytest.raises(ra.api.RtError, match="too many media \\(at most 4\\)"):
+        ra.Scene(make(5, len(d.surfaces) + 3), ra.RT_DEVICE_NONE)
+
+
 def test_examples_camera_matches_oracle_and_unsupported_names_are_refused(ra, ref):
     for name, aspect in (("one-weekend", 1.5), ("cornell", 1.0), ("random-spheres", 1.5), ("two-spheres", 1.5),
                          ("two-perlin", 1.5), ("earth", 1.5), ("cornell-smoke", 1.0), ("final-scene", 1.0)):

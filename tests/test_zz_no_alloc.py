@@ -52,3 +52,27 @@ def test_noalloc_limits_are_errors(ra):
     want, _ = scene.render(1920, 1080, 1)
     assert np.array_equal(big.cpu().numpy(), want)
     scene.close()
+
+
+def test_noalloc_calls_on_two_streams_and_two_scenes_are_ordered(ra):
+    """Every call on a GPU shares that GPU's one scratch array.  Calls issued by one host thread on different
+    streams — and for different scenes — are ordered by the library (an event per GPU: each call's stream waits
+    for the previous call's end), so a long frame on one stream followed at once by a short one on another gives
+    both frames right."""
+    import torch
+
+    a_scene = ra.Scene(ra.load_scene(scene_path("teapot"), 1.5), 0)
+    b_scene = ra.Scene(ra.load_scene(scene_path("quads"), 1.5), 0)
+    s1, s2 = torch.cuda.Stream("cuda:0"), torch.cuda.Stream("cuda:0")
+    fa = torch.zeros((320, 480, 3), dtype=torch.float32, device="cuda:0")
+    fb = torch.zeros((64, 96, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        a_scene.render_device_noalloc(fa.data_ptr(), 480, 320, 8, stream=s1.cuda_stream)   # ~10 M samples in flight ...
+        b_scene.render_device_noalloc(fb.data_ptr(), 96, 64, 1, stream=s2.cuda_stream)     # ... when this one is issued
+    torch.cuda.synchronize()
+    want_a, _ = a_scene.render(480, 320, 8)
+    want_b, _ = b_scene.render(96, 64, 1)
+    assert np.allclose(fa.cpu().numpy(), want_a, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(fb.cpu().numpy(), want_b)
+    a_scene.close(), b_scene.close()
