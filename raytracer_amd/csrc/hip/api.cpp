@@ -98,6 +98,8 @@ struct rt_scene {
         DevCounters* d_counters = nullptr;
         float* d_acc = nullptr;
         size_t acc_bytes = 0;
+        int* d_overflow = nullptr;  // the six-wave build's stack levels beyond LDS (deep mesh trees only)
+        size_t overflow_bytes = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
         hipStream_t last_stream = nullptr;
         bool used = false;
@@ -151,6 +153,7 @@ struct rt_scene {
                 for (void* p : allocations) (void)hipFree(p);
                 for (Slot& sl : slots) {
                     if (sl.d_acc) (void)hipFree(sl.d_acc);
+                    if (sl.d_overflow) (void)hipFree(sl.d_overflow);
                     if (sl.ev0) (void)hipEventDestroy(sl.ev0);
                     if (sl.ev1) (void)hipEventDestroy(sl.ev1);
                     if (sl.done) (void)hipEventDestroy(sl.done);
@@ -1005,9 +1008,19 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                 HIP_CHECK(hipMalloc((void**)&sl.d_acc, need));
                 sl.acc_bytes = need;
             }
-            HIP_CHECK((org == Organisation::Pool ? launch_render_pool : launch_render_persistent)(
-                dev, rp, scene->stack_depth, scene->n_cus, sl.d_acc, d_rgb_sum, sl.d_counters, &sl.d_counters->work, count,
-                stream));
+            if (org == Organisation::Pool) {
+                HIP_CHECK(launch_render_pool(dev, rp, scene->stack_depth, scene->n_cus, sl.d_acc, d_rgb_sum, sl.d_counters,
+                                             &sl.d_counters->work, count, stream));
+            } else {
+                const size_t overflow = persistent_overflow_bytes(dev, scene->stack_depth, scene->n_cus);
+                if (sl.overflow_bytes < overflow) {  // once per slot: the size depends on the scene alone
+                    HIP_CHECK(hipMalloc((void**)&sl.d_overflow, overflow));
+                    sl.overflow_bytes = overflow;
+                    scene->info.device_bytes += overflow;
+                }
+                HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, sl.d_acc, d_rgb_sum, sl.d_counters,
+                                                   &sl.d_counters->work, count, stream, sl.d_overflow));
+            }
         } else {
             if (!scene->wf) scene->wf = std::make_unique<WavefrontState>();
             HIP_CHECK(render_wavefront(*scene->wf, dev, rp, scene->stack_depth, d_rgb_sum, sl.d_counters, count, stream,
@@ -1070,7 +1083,7 @@ int rt_render_device_noalloc(rt_scene* scene, const rt_render_params* params, fl
         if (ordered) HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_v, *scene->noalloc_done, 0));
         HIP_CHECK(launch_render_persistent(dev, rp, scene->stack_depth, scene->n_cus, scene->static_acc, d_rgb_sum,
                                            scene->static_counters, &scene->static_counters->work, false,
-                                           (hipStream_t)stream_v));
+                                           (hipStream_t)stream_v, nullptr));
         if (ordered) HIP_CHECK(hipEventRecord(*scene->noalloc_done, (hipStream_t)stream_v));
         return 0;
     } catch (const std::exception& e) {

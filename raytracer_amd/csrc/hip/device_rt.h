@@ -53,6 +53,19 @@ __device__ __forceinline__ F3 cross(F3 a, F3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ F3 neg(F3 a) { return {-a.x, -a.y, -a.z}; }
+// The same products with every fused multiply-add spelled out and the compiler forbidden to fuse or split anything
+// else: wherever the triangle test is inlined — first slot of a leaf, second slot, the loop over a long leaf, either
+// build of the persistent kernel, the other kernels — a triangle gets the same bits.  (Left to the compiler's
+// contraction, two copies of the test in one kernel rounded differently: a triangle's t depended on its place in its
+// leaf, so host-built and device-built trees gave different images, and a ray slipped between two coplanar triangles.)
+__device__ __forceinline__ float dot_exact(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z));
+}
+__device__ __forceinline__ F3 cross_exact(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+}
 
 struct D3 {
     double x, y, z;
@@ -406,11 +419,22 @@ __device__ __forceinline__ bool hits_tree_bounds(const DevScene& sc, const SlabR
     return tn <= tf;
 }
 
-__device__ __forceinline__ int stack_pop(int* stack, int stride, int& sp) {
+// A lane's traversal stack.  LdsStack: every level in LDS (this lane's column of the [level][lane] array).  A kernel
+// may bring its own type with the same two members (render_persistent.hip's SplitStack keeps only the first levels
+// in LDS).
+struct LdsStack {
+    int* column;
+    int stride;
+    __device__ __forceinline__ void store(int level, int v) const { column[level * stride] = v; }
+    __device__ __forceinline__ int load(int level) const { return column[level * stride]; }
+};
+template <class Stack>
+__device__ __forceinline__ int stack_pop(const Stack& stack, int& sp) {
     if (sp == 0) return kTraversalDone;
     --sp;
-    return stack[sp * stride];
+    return stack.load(sp);
 }
+__device__ __forceinline__ int stack_pop(int* stack, int stride, int& sp) { return stack_pop(LdsStack{stack, stride}, sp); }
 
 // One inner node: test both children's boxes against [tmin, best_t], go to the nearer hit child, defer the
 // other.  Returns the next node (>= 0 inner, < 0 leaf ~first_slot, kTraversalDone).
@@ -429,9 +453,9 @@ __device__ __forceinline__ void child_slab(const uint4 c, const SlabRay& r, floa
     tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
     tf = fminf(fminf(fx, fy), fminf(fz, tmax_pad));
 }
-template <bool STATS>
+template <bool STATS, class Stack>
 __device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, float tmin, float best_t, int node,
-                                         int* stack, int stride, int& sp, TraceStats& st) {
+                                         const Stack& stack, int& sp, TraceStats& st) {
     if (STATS) st.nodes++;
     const uint4 n0 = sc.nodes[2 * node + 0];
     const uint4 n1 = sc.nodes[2 * node + 1];
@@ -443,13 +467,18 @@ __device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, f
     const int c0 = (int)n0.w, c1 = (int)n1.w;
     if (h0 && h1) {
         const bool swap = t1n < t0n;
-        stack[sp * stride] = swap ? c0 : c1;
+        stack.store(sp, swap ? c0 : c1);
         ++sp;
         return swap ? c1 : c0;
     }
     if (h0) return c0;
     if (h1) return c1;
-    return stack_pop(stack, stride, sp);
+    return stack_pop(stack, sp);
+}
+template <bool STATS>
+__device__ __forceinline__ int node_step(const DevScene& sc, const SlabRay& r, float tmin, float best_t, int node,
+                                         int* stack, int stride, int& sp, TraceStats& st) {
+    return node_step<STATS>(sc, r, tmin, best_t, node, LdsStack{stack, stride}, sp, st);
 }
 
 // One leaf slot whose record (p0 p1 p2) is in registers.  Returns true when it was the last slot of its leaf.
@@ -466,17 +495,24 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
     if (TREE == 1 || (TREE == 0 && type == 1u)) {  // triangle, Möller–Trumbore (surfaces.rs:246-279) with host-precomputed edges
         if (STATS) st.tris++;
         const F3 e1 = f3(p1), e2 = f3(p2);
-        const F3 pvec = cross(ray.d, e2);
-        const float det = dot(e1, pvec);
+        const F3 pvec = cross_exact(ray.d, e2);
+        const float det = dot_exact(e1, pvec);
         if (!(-1e-8f < det && det < 1e-8f)) {
             const float inv_det = __builtin_amdgcn_rcpf(det);
             const F3 tvec = tof(ray.o) - f3(p0);  // the f32 origin is re-derived here rather than kept in registers
-            const float u = dot(tvec, pvec) * inv_det;
-            if (u >= 0.f && u <= 1.f) {
-                const F3 qvec = cross(tvec, e1);
-                const float v = dot(ray.d, qvec) * inv_det;
-                if (!(v < 0.f || u + v > 1.f)) {
-                    const float tt = dot(e2, qvec) * inv_det;
+            // The reference's edges are inclusive (u in [0, 1], v >= 0, u + v <= 1, surfaces.rs:262-270) and its f64
+            // barycentrics leave no ray between two triangles that share an edge; f32 ones are off by ~1e-7 either
+            // way, each triangle with its own rounding, and one sample in 4e6 slipped through a shared edge of a flat
+            // mesh (tests/test_gpu_analytic.py::test_furnace_flat_triangle_mesh).  The edges therefore take in
+            // kEdgeSlack more: a ray that close to a shared edge hits both triangles at very nearly the same t, the
+            // nearer one counts (an exact tie goes by rank, like an exact edge hit in the reference).
+            constexpr float kEdgeSlack = 0x1p-20f;
+            const float u = dot_exact(tvec, pvec) * inv_det;
+            if (u >= -kEdgeSlack && u <= 1.f + kEdgeSlack) {
+                const F3 qvec = cross_exact(tvec, e1);
+                const float v = dot_exact(ray.d, qvec) * inv_det;
+                if (!(v < -kEdgeSlack || u + v > 1.f + kEdgeSlack)) {
+                    const float tt = dot_exact(e2, qvec) * inv_det;
                     if (!(tt < 1e-4f) && tmin <= tt) t = tt, bu = u, bv = v;
                 }
             }

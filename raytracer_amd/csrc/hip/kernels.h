@@ -6,9 +6,12 @@
 
 namespace rt {
 
+// d_stack_overflow: persistent_overflow_bytes() of device memory for the six-wave build's deep stack levels, or null
+// (the launch then runs the build that keeps the whole stack in LDS)
 hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& rp, uint32_t tree_depth,
                                     uint32_t n_cus, float* d_acc, float* d_rgb_sum, DevCounters* counters,
-                                    uint32_t* work_counter, bool stats, hipStream_t stream);
+                                    uint32_t* work_counter, bool stats, hipStream_t stream, int* d_stack_overflow);
+size_t persistent_overflow_bytes(const DevScene& sc, uint32_t tree_depth, uint32_t n_cus);
 // bytes of the tile-planar accumulator the persistent kernel adds into (d_acc above)
 size_t persistent_acc_bytes(uint32_t width, uint32_t height);
 // rt_render_device_noalloc: the largest frame (in 8x8 tiles; 1920x1080 is 32 400) whose accumulator fits the

@@ -14,9 +14,24 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "device_rt.h"
 #include "kernels.h"
+
+// This file is compiled twice (csrc/Makefile).  RT_PERSISTENT_VARIANT == 0, the default: everything.
+// RT_PERSISTENT_VARIANT == 1 ("w6"): only the triangles-only lean kernel, built without SLP vectorisation
+// (-fno-slp-vectorize: no v_pk_*_f32 and none of the moves that feed them — 87 VGPRs instead of 95) for SIX waves per
+// SIMD (80 VGPRs, 8 dwords spilled), and its launcher.  It serves the mesh scenes whose blocks need little enough LDS
+// for six of them to share a CU (trees of up to 18 levels: teapot.yaml, dual.yaml: +6 %); where LDS holds a CU to
+// five blocks anyway (lucy.yaml's 22 levels) the spills cost 6-8 % and the default build runs.  The kernels of the two
+// builds differ in their last template argument, hence in their names.
+#ifndef RT_PERSISTENT_VARIANT
+#define RT_PERSISTENT_VARIANT 0
+#endif
+#ifndef RT_W6_WAVES
+#define RT_W6_WAVES 6
+#endif
 
 namespace rt {
 
@@ -70,7 +85,14 @@ struct PersistentPlan {
     // each — direction (3), generator state (2), and where the scene needs them lens sample (2) and shutter time (1).
     uint32_t stack_levels;
     uint32_t gen_words;
+    // The six-wave build keeps at most kLdsStackCap levels of the stack in LDS; a lane that defers more children than
+    // that — trees deeper than kLdsStackCap + 1 only — keeps the rest here: [level - kLdsStackCap][lane of the launch].
+    int* stack_overflow;
 };
+#ifndef RT_LDS_STACK_CAP
+#define RT_LDS_STACK_CAP 16
+#endif
+constexpr uint32_t kLdsStackCap = RT_LDS_STACK_CAP;
 // the kernel's arguments as the kernarg segment lays them out (reload_kernarg)
 struct PersistentArgs {
     DevScene sc;
@@ -79,6 +101,24 @@ struct PersistentArgs {
     float* acc;
     DevCounters* counters;
     uint32_t* work_counter;
+};
+// The six-wave build's traversal stack.  What bounds a CU to five blocks on lucy.yaml is LDS, 21 KB of each block's
+// 31 KB being the stack of a 22-level tree, whose lower levels a lane hardly ever reaches: the first kLdsStackCap
+// levels stay in LDS ([level][lane]), deeper ones go to the launch's overflow array in memory (the address is worked
+// out there and then from the kernel's arguments: nothing of it lives in registers along the hot path).
+struct SplitStack {
+    int* column;  // this lane's column of the LDS array, stride kBlock
+    __device__ __forceinline__ int* overflow_slot(int level) const {
+        int* base = reload_kernarg<int*>(offsetof(PersistentArgs, plan) + offsetof(PersistentPlan, stack_overflow));
+        return base + (size_t)(level - (int)kLdsStackCap) * ((size_t)gridDim.x * kBlock) + (blockIdx.x * kBlock + threadIdx.x);
+    }
+    __device__ __forceinline__ void store(int level, int v) const {
+        if (level < (int)kLdsStackCap) column[level * kBlock] = v;
+        else *overflow_slot(level) = v;
+    }
+    __device__ __forceinline__ int load(int level) const {
+        return level < (int)kLdsStackCap ? column[level * kBlock] : *overflow_slot(level);
+    }
 };
 constexpr uint32_t kGenLens = 5, kGenTime = 7;  // first word of the lens sample / of the shutter time in a batch
 
@@ -171,13 +211,14 @@ __device__ __attribute__((noinline)) void draw_batch(const void* kernarg, float*
 // Waves per SIMD each build is compiled for (the register budget that follows from it): every one measured, see the
 // macros above and DESIGN §4.1 "builds".
 constexpr int waves_per_simd(bool ext, bool media, int tree, bool noise) {
+    if (RT_PERSISTENT_VARIANT == 1) return RT_W6_WAVES;
     if (media) return RT_MEDIA_WAVES;
     if (!ext) return tree == 4 ? RT_NOTREE_WAVES : (tree != 0 ? RT_LEAN_WAVES : RT_MIN_WAVES);
     if (noise) return RT_EXT_WAVES;
     return tree == 4 ? RT_EXT_NOTREE_WAVES : (tree != 0 ? RT_EXT_PLAIN_WAVES : RT_EXT_WAVES);
 }
 
-template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE, bool NOISE = true>
+template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE, bool NOISE = true, int VARIANT = RT_PERSISTENT_VARIANT>
 __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
@@ -186,7 +227,10 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) vo
     uint4* lds_loose = lds_dyn;
     int* lds_stack = (int*)(lds_dyn + sc.n_loose * kLooseRecQuads);
     float* lds_acc = (float*)(lds_stack + plan.stack_levels * kBlock);
-    int* stack = lds_stack + threadIdx.x;
+    // (every level in LDS; the six-wave build keeps the levels beyond kLdsStackCap in memory, see SplitStack, and
+    // takes the code that knows about them only on the trips in which a lane of the wave is that deep)
+    const LdsStack stack{lds_stack + threadIdx.x, kBlock};
+    const SplitStack deep_stack{lds_stack + threadIdx.x};
     for (uint32_t i = threadIdx.x; i < sc.n_loose * kLooseRecQuads; i += kBlock) lds_loose[i] = sc.loose_rec[i];
     // radiance sums of the tile this wave's current chunk belongs to (3 x 64 floats per wave)
     float* wacc = lds_acc + (threadIdx.x >> 6) * 192;
@@ -247,15 +291,21 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) vo
             if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
             if (STATS && exhausted) drain_trips[0]++, drain_lanes[0] += n_node;
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
+            if (VARIANT == 1 && __any(sp + RT_NODE_STEPS > (int)kLdsStackCap)) {  // a push or pop may pass the LDS levels
 #pragma unroll 1
-            for (int k = 0; k < RT_NODE_STEPS; ++k)
-                if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, kBlock, sp, st);
+                for (int k = 0; k < RT_NODE_STEPS; ++k)
+                    if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, deep_stack, sp, st);
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < RT_NODE_STEPS; ++k)
+                    if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, sp, st);
+            }
         } else if (!run_shade) {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
             if (node < 0) {
                 leaf_step<STATS, EXT, TREE>(sc, ray, sr, 0.001f, ~node, best, st);
-                node = stack_pop(stack, kBlock, sp);
+                node = (VARIANT == 1 && sp > (int)kLdsStackCap) ? stack_pop(deep_stack, sp) : stack_pop(stack, sp);
             }
         } else {
             if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
@@ -424,6 +474,27 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) vo
     }
 }
 
+#if RT_PERSISTENT_VARIANT == 1
+// the w6 build's launcher: the triangles-only lean kernel, by counting build and sampler
+hipError_t launch_persistent_w6(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
+                                size_t lds, float* d_acc, DevCounters* counters, uint32_t* work_counter, bool stats,
+                                hipStream_t stream) {
+#define RT_LAUNCH_W6(STATS_, DIRECT_)                                                                                       \
+    hipLaunchKernelGGL((render_persistent_kernel<STATS_, DIRECT_, false, false, 1>), dim3(blocks), dim3(kBlock), lds, stream, \
+                       sc, rp, plan, d_acc, counters, work_counter)
+    const bool direct = rp.sampler != 0;
+    if (stats && direct) RT_LAUNCH_W6(true, true);
+    else if (stats) RT_LAUNCH_W6(true, false);
+    else if (direct) RT_LAUNCH_W6(false, true);
+    else RT_LAUNCH_W6(false, false);
+#undef RT_LAUNCH_W6
+    return hipGetLastError();
+}
+#else
+hipError_t launch_persistent_w6(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
+                                size_t lds, float* d_acc, DevCounters* counters, uint32_t* work_counter, bool stats,
+                                hipStream_t stream);
+
 // tile-planar accumulator -> the caller's row-major interleaved framebuffer (row 0 = top, main.rs:158)
 __global__ void resolve_kernel(const float* __restrict__ acc, uint32_t width, uint32_t height, uint32_t tiles_x,
                                float* __restrict__ rgb_sum) {
@@ -470,6 +541,9 @@ static void launch_one(const DevScene& sc, const DevRenderParams& rp, const Pers
 #undef RT_LAUNCH_PLAIN
 }
 
+// Six 256-thread blocks share a CU's 160 KB of LDS when each needs at most this much (allocated in 512-byte steps)
+constexpr size_t kLdsForSixBlocks = (160u * 1024u / 6u) / 512u * 512u;
+
 static hipError_t launch_any(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
                              float* d_acc, DevCounters* counters, uint32_t* work_counter, bool stats, hipStream_t stream) {
     const bool direct = rp.sampler != 0;
@@ -480,10 +554,19 @@ static hipError_t launch_any(const DevScene& sc, const DevRenderParams& rp, cons
     return hipGetLastError();
 }
 
+static uint32_t persistent_grid_limit(uint32_t n_cus) { return n_cus * 8u * (256u / kBlock); }
+
+size_t persistent_overflow_bytes(const DevScene& sc, uint32_t tree_depth, uint32_t n_cus) {
+    const uint32_t levels = std::max(tree_depth, 2u) - 1u;
+    if (sc.ext || !sc.has_tree || sc.tree_kind != 1u || levels <= kLdsStackCap) return 0;
+    return (size_t)(levels - kLdsStackCap) * persistent_grid_limit(n_cus) * kBlock * sizeof(int);
+}
+
 hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& rp, uint32_t tree_depth,
                                     uint32_t n_cus, float* d_acc, float* d_rgb_sum, DevCounters* counters,
-                                    uint32_t* work_counter, bool stats, hipStream_t stream) {
+                                    uint32_t* work_counter, bool stats, hipStream_t stream, int* d_stack_overflow) {
     PersistentPlan plan;
+    plan.stack_overflow = nullptr;
     // (36 for the large triangle meshes, 44 for the small ones — trees of up to 18 levels, which stay in the caches: a
     // node trip is then cheap beside a shade trip, and the shade stage had better wait for more lanes: teapot.yaml
     // +3.3 %, dual.yaml +1.6 %, where lucy.yaml would lose 2.7 %; trees of spheres and quads, whose rays nearly all
@@ -521,13 +604,25 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     if (plan.n_chunks == 0) return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);
     // Enough blocks to fill every CU at the occupancy the kernel's registers and LDS allow; surplus blocks are
     // harmless (they start when a slot frees up and find the counter exhausted).
-    const uint32_t blocks = std::min<uint32_t>(n_cus * 8u * (256u / kBlock), (plan.n_chunks + 3u) / 4u * (256u / kBlock));
+    const uint32_t blocks = std::min<uint32_t>(persistent_grid_limit(n_cus), (plan.n_chunks + 3u) / 4u * (256u / kBlock));
     // near-first traversal keeps at most (depth - 1) deferred children
     // (LDS per block at ~1 KB per level: up to 27 levels -> 5 blocks per CU, 35 -> 4, 48 -> 3, 56 -> 2)
     if (tree_depth > 56) return hipErrorInvalidValue;  // caller reports "BVH deeper than the traversal stack"
     plan.stack_levels = std::max(tree_depth, 2u) - 1u;
     plan.gen_words = sc.ext ? kGenTime + 1u : (sc.cam.lens_radius != 0.f ? kGenLens + 2u : kGenLens);
-    e = launch_any(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
+    // Mesh scenes whose blocks leave room for a sixth per CU run the six-wave build (see the top of this file), with
+    // the stack's levels beyond kLdsStackCap in the overflow array when the tree is deeper than that (a caller
+    // without one — rt_render_device_noalloc — then stays with the default build).
+    static const bool no_w6 = getenv("RT_NO_W6") != nullptr, force_w6 = getenv("RT_FORCE_W6") != nullptr;  // A/B aids
+    PersistentPlan w6 = plan;
+    w6.stack_levels = std::min(plan.stack_levels, kLdsStackCap);
+    w6.stack_overflow = d_stack_overflow;
+    const bool w6_fits = !sc.ext && sc.has_tree && sc.tree_kind == 1u && persistent_lds_bytes(sc, w6) <= kLdsForSixBlocks &&
+                         (plan.stack_levels <= kLdsStackCap || d_stack_overflow != nullptr);
+    if ((w6_fits && !no_w6) || (force_w6 && !sc.ext && sc.has_tree && sc.tree_kind == 1u))
+        e = launch_persistent_w6(sc, rp, w6, blocks, persistent_lds_bytes(sc, w6), d_acc, counters, work_counter, stats, stream);
+    else
+        e = launch_any(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     if (e != hipSuccess) return e;
     return launch_resolve(d_acc, rp.width, rp.height, d_rgb_sum, stream);
 }
@@ -599,5 +694,6 @@ hipError_t launch_tonemap(const float* d_rgb_sum, uint32_t n_values, double n_sa
     hipLaunchKernelGGL(tonemap_kernel, dim3(blocks), dim3(256), 0, stream, d_rgb_sum, n_values, n_samples, d_out);
     return hipGetLastError();
 }
+#endif  // RT_PERSISTENT_VARIANT
 
 }  // namespace rt
