@@ -19,20 +19,12 @@
 #include "device_rt.h"
 #include "kernels.h"
 
-// This file is compiled twice (csrc/Makefile).  RT_PERSISTENT_VARIANT == 0, the default: everything.
-// RT_PERSISTENT_VARIANT == 1 ("w6"): only the triangles-only lean kernel, built without SLP vectorisation
-// (-fno-slp-vectorize: no v_pk_*_f32 and none of the moves that feed them — 87 VGPRs instead of 95) for SIX waves per
-// SIMD (80 VGPRs, 8 dwords spilled), and its launcher.  It serves the mesh scenes whose blocks need little enough LDS
-// for six of them to share a CU (trees of up to 18 levels: teapot.yaml, dual.yaml: +6 %); where LDS holds a CU to
-// five blocks anyway (lucy.yaml's 22 levels) the spills cost 6-8 % and the default build runs.  The kernels of the two
-// builds differ in their last template argument, hence in their names.
-#ifndef RT_PERSISTENT_VARIANT
-#define RT_PERSISTENT_VARIANT 0
-#endif
-#ifndef RT_W6_WAVES
-#define RT_W6_WAVES 6
-#endif
-
+// The triangles-only lean kernel exists twice (last template argument, SIX): compiled for five waves per SIMD
+// (96 VGPRs) with the whole traversal stack in LDS, and for SIX (80 VGPRs, 12 dwords spilled) with at most
+// kLdsStackCap stack levels in LDS and the deeper ones in memory (SplitStack) — what holds a CU to five blocks on
+// lucy.yaml is LDS, 21 KB of each block's 31 KB being the stack of a 22-level tree.  The six-wave kernel serves the
+// mesh scenes whose blocks then fit six to a CU: lucy.yaml +5 %, teapot.yaml +6 %, dual.yaml +6 %, cornell_lucy.yaml
+// +8 %.
 namespace rt {
 
 #ifndef RT_BLOCK
@@ -89,10 +81,7 @@ struct PersistentPlan {
     // that — trees deeper than kLdsStackCap + 1 only — keeps the rest here: [level - kLdsStackCap][lane of the launch].
     int* stack_overflow;
 };
-#ifndef RT_LDS_STACK_CAP
-#define RT_LDS_STACK_CAP 16
-#endif
-constexpr uint32_t kLdsStackCap = RT_LDS_STACK_CAP;
+constexpr uint32_t kLdsStackCap = 16;
 // the kernel's arguments as the kernarg segment lays them out (reload_kernarg)
 struct PersistentArgs {
     DevScene sc;
@@ -210,16 +199,16 @@ __device__ __attribute__((noinline)) void draw_batch(const void* kernarg, float*
 
 // Waves per SIMD each build is compiled for (the register budget that follows from it): every one measured, see the
 // macros above and DESIGN §4.1 "builds".
-constexpr int waves_per_simd(bool ext, bool media, int tree, bool noise) {
-    if (RT_PERSISTENT_VARIANT == 1) return RT_W6_WAVES;
+constexpr int waves_per_simd(bool ext, bool media, int tree, bool noise, bool six) {
+    if (six) return 6;
     if (media) return RT_MEDIA_WAVES;
     if (!ext) return tree == 4 ? RT_NOTREE_WAVES : (tree != 0 ? RT_LEAN_WAVES : RT_MIN_WAVES);
     if (noise) return RT_EXT_WAVES;
     return tree == 4 ? RT_EXT_NOTREE_WAVES : (tree != 0 ? RT_EXT_PLAIN_WAVES : RT_EXT_WAVES);
 }
 
-template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE, bool NOISE = true, int VARIANT = RT_PERSISTENT_VARIANT>
-__global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
+template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE, bool NOISE = true, bool SIX = false>
+__global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX)) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
                                                                    DevCounters* __restrict__ counters,
                                                                    uint32_t* __restrict__ work_counter) {
@@ -291,7 +280,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) vo
             if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
             if (STATS && exhausted) drain_trips[0]++, drain_lanes[0] += n_node;
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
-            if (VARIANT == 1 && __any(sp + RT_NODE_STEPS > (int)kLdsStackCap)) {  // a push or pop may pass the LDS levels
+            if (SIX && __any(sp + RT_NODE_STEPS > (int)kLdsStackCap)) {  // a push or pop may pass the LDS levels
 #pragma unroll 1
                 for (int k = 0; k < RT_NODE_STEPS; ++k)
                     if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, deep_stack, sp, st);
@@ -305,7 +294,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) vo
             if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
             if (node < 0) {
                 leaf_step<STATS, EXT, TREE>(sc, ray, sr, 0.001f, ~node, best, st);
-                node = (VARIANT == 1 && sp > (int)kLdsStackCap) ? stack_pop(deep_stack, sp) : stack_pop(stack, sp);
+                node = (SIX && sp > (int)kLdsStackCap) ? stack_pop(deep_stack, sp) : stack_pop(stack, sp);
             }
         } else {
             if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
@@ -474,26 +463,21 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE)) vo
     }
 }
 
-#if RT_PERSISTENT_VARIANT == 1
-// the w6 build's launcher: the triangles-only lean kernel, by counting build and sampler
-hipError_t launch_persistent_w6(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
-                                size_t lds, float* d_acc, DevCounters* counters, uint32_t* work_counter, bool stats,
-                                hipStream_t stream) {
-#define RT_LAUNCH_W6(STATS_, DIRECT_)                                                                                       \
-    hipLaunchKernelGGL((render_persistent_kernel<STATS_, DIRECT_, false, false, 1>), dim3(blocks), dim3(kBlock), lds, stream, \
-                       sc, rp, plan, d_acc, counters, work_counter)
+// the six-wave kernel's launcher: the triangles-only lean kernel, by counting build and sampler
+static hipError_t launch_persistent_six(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
+                                        size_t lds, float* d_acc, DevCounters* counters, uint32_t* work_counter, bool stats,
+                                        hipStream_t stream) {
+#define RT_LAUNCH_SIX(STATS_, DIRECT_)                                                                                    \
+    hipLaunchKernelGGL((render_persistent_kernel<STATS_, DIRECT_, false, false, 1, true, true>), dim3(blocks), dim3(kBlock), \
+                       lds, stream, sc, rp, plan, d_acc, counters, work_counter)
     const bool direct = rp.sampler != 0;
-    if (stats && direct) RT_LAUNCH_W6(true, true);
-    else if (stats) RT_LAUNCH_W6(true, false);
-    else if (direct) RT_LAUNCH_W6(false, true);
-    else RT_LAUNCH_W6(false, false);
-#undef RT_LAUNCH_W6
+    if (stats && direct) RT_LAUNCH_SIX(true, true);
+    else if (stats) RT_LAUNCH_SIX(true, false);
+    else if (direct) RT_LAUNCH_SIX(false, true);
+    else RT_LAUNCH_SIX(false, false);
+#undef RT_LAUNCH_SIX
     return hipGetLastError();
 }
-#else
-hipError_t launch_persistent_w6(const DevScene& sc, const DevRenderParams& rp, const PersistentPlan& plan, uint32_t blocks,
-                                size_t lds, float* d_acc, DevCounters* counters, uint32_t* work_counter, bool stats,
-                                hipStream_t stream);
 
 // tile-planar accumulator -> the caller's row-major interleaved framebuffer (row 0 = top, main.rs:158)
 __global__ void resolve_kernel(const float* __restrict__ acc, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -613,14 +597,14 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // Mesh scenes whose blocks leave room for a sixth per CU run the six-wave build (see the top of this file), with
     // the stack's levels beyond kLdsStackCap in the overflow array when the tree is deeper than that (a caller
     // without one — rt_render_device_noalloc — then stays with the default build).
-    static const bool no_w6 = getenv("RT_NO_W6") != nullptr, force_w6 = getenv("RT_FORCE_W6") != nullptr;  // A/B aids
+    static const bool no_w6 = getenv("RT_NO_W6") != nullptr;  // A/B aid: the five-wave kernel throughout
     PersistentPlan w6 = plan;
     w6.stack_levels = std::min(plan.stack_levels, kLdsStackCap);
     w6.stack_overflow = d_stack_overflow;
     const bool w6_fits = !sc.ext && sc.has_tree && sc.tree_kind == 1u && persistent_lds_bytes(sc, w6) <= kLdsForSixBlocks &&
                          (plan.stack_levels <= kLdsStackCap || d_stack_overflow != nullptr);
-    if ((w6_fits && !no_w6) || (force_w6 && !sc.ext && sc.has_tree && sc.tree_kind == 1u))
-        e = launch_persistent_w6(sc, rp, w6, blocks, persistent_lds_bytes(sc, w6), d_acc, counters, work_counter, stats, stream);
+    if (w6_fits && !no_w6)
+        e = launch_persistent_six(sc, rp, w6, blocks, persistent_lds_bytes(sc, w6), d_acc, counters, work_counter, stats, stream);
     else
         e = launch_any(sc, rp, plan, blocks, d_acc, counters, work_counter, stats, stream);
     if (e != hipSuccess) return e;
@@ -694,6 +678,5 @@ hipError_t launch_tonemap(const float* d_rgb_sum, uint32_t n_values, double n_sa
     hipLaunchKernelGGL(tonemap_kernel, dim3(blocks), dim3(256), 0, stream, d_rgb_sum, n_values, n_samples, d_out);
     return hipGetLastError();
 }
-#endif  // RT_PERSISTENT_VARIANT
 
 }  // namespace rt
