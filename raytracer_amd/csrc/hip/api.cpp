@@ -475,6 +475,18 @@ uint32_t half_bits_up(uint32_t e) {
     return ((uint32_t)(top + 15) << 10) | mant;
 }
 
+// [0, n) in contiguous chunks on up to `max_tasks` threads (the caller's included); fn(begin, end) writes disjoint
+// elements.  Small ranges stay on the calling thread.
+template <class F>
+void parallel_chunks(size_t n, size_t min_chunk, size_t max_tasks, F&& fn) {
+    const size_t tasks = std::max<size_t>(1, std::min(max_tasks, n / std::max<size_t>(min_chunk, 1)));
+    if (tasks == 1) return fn((size_t)0, n);
+    std::vector<std::future<void>> jobs;
+    for (size_t t = 1; t < tasks; ++t) jobs.push_back(run_async([&fn, n, t, tasks]() { fn(n * t / tasks, n * (t + 1) / tasks); }));
+    fn((size_t)0, n / tasks);
+    for (auto& j : jobs) j.get();
+}
+
 // Render tree + loose list -> f32 arrays of the render kernels.
 void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     const size_t n_surf = d.n_surfaces;
@@ -548,12 +560,14 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         put_child(0, 0, rb.nodes[0].box, ~0);
         s.nodes[1] = uint4{0x0000ffffu, 0x0000ffffu, 0x0000ffffu, (uint32_t)~(int32_t)n_tree};  // centre 65535, half-extent +0.0
     } else if (s.has_tree) {
-        for (size_t i = 0; i < rb.nodes.size(); ++i) {
-            const BvhNode& n = rb.nodes[i];
-            if (n.is_leaf()) continue;
-            put_child(ft.inner_id[i], 0, rb.nodes[n.left].box, ft.child_ref(rb, n.left));
-            put_child(ft.inner_id[i], 1, rb.nodes[n.right].box, ft.child_ref(rb, n.right));
-        }
+        parallel_chunks(rb.nodes.size(), 8192, 8, [&](size_t begin, size_t end) {
+            for (size_t i = begin; i < end; ++i) {
+                const BvhNode& n = rb.nodes[i];
+                if (n.is_leaf()) continue;
+                put_child(ft.inner_id[i], 0, rb.nodes[n.left].box, ft.child_ref(rb, n.left));
+                put_child(ft.inner_id[i], 1, rb.nodes[n.right].box, ft.child_ref(rb, n.right));
+            }
+        });
         s.stack_depth = rb.max_depth;
     }
 
@@ -563,7 +577,8 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     s.prims.assign(3 * (std::max<size_t>(n_slots, 1) + 1), float4{0, 0, 0, 0});  // + one slot of padding (leaf_step)
     s.tri_shade.assign(3 * std::max<size_t>(n_slots, 1), float4{0, 0, 0, 0});
     s.slot_surface.assign(std::max<size_t>(n_slots, 1), -1);
-    for (size_t slot = 0; slot < n_tree; ++slot) {
+    parallel_chunks(n_tree, 8192, 8, [&](size_t slot_begin, size_t slot_end) {
+    for (size_t slot = slot_begin; slot < slot_end; ++slot) {
         const int32_t sid = rb.order[slot];
         const rt_surface_ref& ref = d.surfaces[sid];
         s.slot_surface[slot] = sid;
@@ -585,6 +600,7 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
         }
         p[1].w = int_bits(rank[sid]);
     }
+    });
     // The dummy slot is read by whatever test the kernel build compiles in (the spheres-only and quads-only builds
     // ignore the type bits): make it a record that test can never hit — a triangle with zero edges (det = 0), the
     // extra sphere with a NaN radius (disc > 0 fails), the extra quad with a zero normal (|denom| < 1e-8) below.

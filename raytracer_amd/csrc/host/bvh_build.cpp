@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <future>
 
 namespace rt {
@@ -39,9 +40,49 @@ int32_t splice(Bvh& dst, const Bvh& src) {
 
 struct Builder {
     std::vector<Item>& items;
-    std::vector<Aabb> merge_left, merge_right;  // scratch for the sweep
+    std::vector<double> right_area;             // scratch for the sweep
+    std::vector<uint64_t> keys, keys_tmp;       // scratch for the sort
+    std::vector<uint32_t> perm, perm_tmp;
+    std::vector<Item> sorted;
     Bvh* out = nullptr;
     explicit Builder(std::vector<Item>& it, Bvh* o) : items(it), out(o) {}
+
+    // The reference's `surfaces.sort_by(|a, b| a.min[axis].partial_cmp(b.min[axis]))` (bvh.rs:209-218): a STABLE sort,
+    // whose treatment of equal keys decides the tree.  Same result as std::stable_sort with `<` on the keys, three
+    // times faster on a mesh: a least-significant-digit radix sort — stable by construction — of (key, position)
+    // pairs, byte by byte, skipping the bytes all keys share, then one gather of the 56-byte items.  Keys are the
+    // doubles mapped to integers of the same order (-0.0 first folded into +0.0, which `<` cannot tell apart).
+    void stable_sort_by_min(size_t first, size_t n, int axis) {
+        if (n < 96) {
+            std::stable_sort(items.begin() + first, items.begin() + first + n,
+                             [axis](const Item& a, const Item& b) { return a.box.lo.get(axis) < b.box.lo.get(axis); });
+            return;
+        }
+        keys.resize(n), keys_tmp.resize(n), perm.resize(n), perm_tmp.resize(n), sorted.resize(n);
+        uint64_t all_or = 0, all_and = ~0ull;
+        for (size_t i = 0; i < n; ++i) {
+            const double v = items[first + i].box.lo.get(axis) + 0.0;  // -0.0 + 0.0 == +0.0
+            uint64_t u;
+            std::memcpy(&u, &v, 8);
+            u ^= (u >> 63) ? ~0ull : 0x8000000000000000ull;
+            keys[i] = u, perm[i] = (uint32_t)i;
+            all_or |= u, all_and &= u;
+        }
+        const uint64_t varies = all_or ^ all_and;  // bits that are not the same in every key
+        for (int shift = 0; shift < 64; shift += 8) {
+            if (((varies >> shift) & 0xffu) == 0) continue;
+            size_t count[257] = {0};
+            for (size_t i = 0; i < n; ++i) count[((keys[i] >> shift) & 0xffu) + 1]++;
+            for (int b = 0; b < 256; ++b) count[b + 1] += count[b];
+            for (size_t i = 0; i < n; ++i) {
+                const size_t dst = count[(keys[i] >> shift) & 0xffu]++;
+                keys_tmp[dst] = keys[i], perm_tmp[dst] = perm[i];
+            }
+            keys.swap(keys_tmp), perm.swap(perm_tmp);
+        }
+        for (size_t i = 0; i < n; ++i) sorted[i] = items[first + perm[i]];
+        std::copy(sorted.begin(), sorted.begin() + n, items.begin() + first);
+    }
 
     int32_t make_leaf(size_t first, size_t count, uint32_t depth) {
         BvhNode n;
@@ -56,27 +97,27 @@ struct Builder {
         return (int32_t)out->nodes.size() - 1;
     }
 
-    // SAHSplitStrategy::split_at, bvh.rs:131-174.  Returns 0 for "do not split".
+    // SAHSplitStrategy::split_at, bvh.rs:131-174.  Returns 0 for "do not split".  The reference builds two arrays of
+    // merged boxes (prefixes from the left, from the right) and reads a pair of them per candidate; the same boxes,
+    // merged in the same order, are produced here as one array of suffix AREAS and a running prefix box — an eighth
+    // of the memory traffic, the very same costs.
     size_t sah_split(size_t first, size_t n) {
         if (n <= 1) return 0;
-        merge_left.resize(n);
-        merge_right.resize(n);
-        for (size_t i = 0; i < n; ++i) {
-            merge_left[i] = items[first + i].box;
-            merge_right[i] = items[first + n - 1 - i].box;
+        right_area.resize(n);  // right_area[k]: surface area of the boxes k .. n-1 merged from the right end
+        Aabb acc = items[first + n - 1].box;
+        right_area[n - 1] = acc.surface_area();
+        for (size_t k = n - 1; k-- > 0;) {
+            acc = items[first + k].box.merge(acc);
+            right_area[k] = acc.surface_area();
         }
-        for (size_t i = 1; i < n; ++i) {
-            merge_left[i] = merge_left[i].merge(merge_left[i - 1]);
-            merge_right[i] = merge_right[i].merge(merge_right[i - 1]);
-        }
-        double no_split_cost = merge_left[n - 1].surface_area() * (double)n * kIntersectCost;
+        const double no_split_cost = right_area[0] * (double)n * kIntersectCost;  // all n boxes merged
         size_t best = 0;
         double best_cost = 0.0;
+        Aabb left = items[first].box;  // boxes 0 .. s-1
         for (size_t s = 1; s + 1 < n; ++s) {  // (1..len-1): the last candidate is len-2
-            const Aabb& l = merge_left[s - 1];
-            const Aabb& r = merge_right[n - s - 1];
-            double cost = kTraversalCost + l.surface_area() * (double)s * kIntersectCost +
-                          r.surface_area() * (double)(n - s) * kIntersectCost;
+            if (s > 1) left = items[first + s - 1].box.merge(left);
+            double cost = kTraversalCost + left.surface_area() * (double)s * kIntersectCost +
+                          right_area[s] * (double)(n - s) * kIntersectCost;
             if (best == 0 || cost < best_cost) {  // min_by keeps the FIRST minimum
                 best = s;
                 best_cost = cost;
@@ -99,8 +140,7 @@ struct Builder {
         int axis = 0;
         if (span.get(axis) < span.get(1)) axis = 1;
         if (span.get(axis) < span.get(2)) axis = 2;
-        std::stable_sort(items.begin() + first, items.begin() + first + n,
-                         [axis](const Item& a, const Item& b) { return a.box.lo.get(axis) < b.box.lo.get(axis); });
+        stable_sort_by_min(first, n, axis);
         size_t split = sah_split(first, n);
         if (split == 0) return make_leaf(first, n, depth);
         int32_t self = (int32_t)out->nodes.size();
