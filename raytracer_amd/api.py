@@ -15,8 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # override: A/B of kernel builds
 
-RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
-RT_SURF_SPHERE, RT_SURF_TRIANGLE, RT_SURF_QUAD = 0, 1, 2
+RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT_ISOTROPIC = 0, 1, 2, 3, 4
+RT_SURF_SPHERE, RT_SURF_TRIANGLE, RT_SURF_QUAD, RT_SURF_MEDIUM = 0, 1, 2, 3
 RT_KERNEL_PERSISTENT, RT_KERNEL_WAVEFRONT, RT_KERNEL_POOL = 0, 1, 2
 RT_DEVICE_CURRENT, RT_DEVICE_NONE = -1, -2
 RT_SAMPLER_REFERENCE, RT_SAMPLER_DIRECT = 0, 1

@@ -55,6 +55,13 @@ constexpr int kBlock = RT_BLOCK;
 #ifndef RT_MEDIA_WAVES
 #define RT_MEDIA_WAVES 3  // the build with constant media: 168 VGPRs (4 waves spill 56 dwords: -8..-12 %; 2 waves: -24 %)
 #endif
+// tools/dynamic_isa.py compiles this file with -DRT_REGION_MARKERS: comments in the instruction stream that say which
+// stage the code after them belongs to (no instruction, no effect on the product build, which does not define it)
+#ifdef RT_REGION_MARKERS
+#define RT_REGION(name) asm volatile("; RT_REGION " name)
+#else
+#define RT_REGION(name) ((void)0)
+#endif
 constexpr uint32_t kChunkStrata = 16;  // strata per chunk in the first phase (a chunk is 64 pixels x this many strata)
 constexpr int kPhases = 5;
 
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
     // execute a trip all do the same small piece of work (one node, one primitive, or one shade+raygen),
     // whatever mix of cheap sky/ground rays and long mesh traversals the wave holds.
     while (true) {
+        RT_REGION("select");
         const unsigned long long m_shade = __ballot(node == kStageShade);
         const unsigned long long m_leaf = __ballot(node < 0);
         const unsigned long long m_node = __ballot(node >= 0 && node < kStageIdle);
@@ -280,18 +288,23 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
             if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
             if (STATS && exhausted) drain_trips[0]++, drain_lanes[0] += n_node;
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
+            RT_REGION("node");
             if (SIX && __any(sp + RT_NODE_STEPS > (int)kLdsStackCap)) {  // a push or pop may pass the LDS levels
+                RT_REGION("node.deep");
 #pragma unroll 1
                 for (int k = 0; k < RT_NODE_STEPS; ++k)
                     if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, deep_stack, sp, st);
             } else {
+                RT_REGION("node");
 #pragma unroll 1
                 for (int k = 0; k < RT_NODE_STEPS; ++k)
                     if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, sp, st);
             }
+            RT_REGION("select");
         } else if (!run_shade) {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
+            RT_REGION("leaf");
             if (node < 0) {
                 leaf_step<STATS, EXT, TREE>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = (SIX && sp > (int)kLdsStackCap) ? stack_pop(deep_stack, sp) : stack_pop(stack, sp);
@@ -299,6 +312,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
         } else {
             if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
             if (STATS && exhausted) drain_trips[2]++, drain_lanes[2] += n_shade;
+            RT_REGION("shade.bounce");
             const bool mine = node == kStageShade;
             // The scene's parameters as this stage sees them: read again from the kernel's arguments (scalar loads of
             // the members used below) rather than kept in SGPRs across the node and leaf stages — see reload_uniform.
@@ -355,6 +369,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
                 sub_cycles[0] += t - t_part, t_part = t;
             }
             // ---- regenerate: lanes without a path take the next samples of the chunk (uniform control flow)
+            RT_REGION("shade.regenerate");
             unsigned long long need = __ballot(mine && !alive);
             while (need != 0ull && !exhausted) {
                 if (next_j >= chunk_total) {
@@ -406,6 +421,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
             }
             // ---- start the next segment's trace: loose spheres/quads now (all these lanes in lockstep), the
             // tree through the node/leaf stages
+            RT_REGION("shade.loose");
             if (mine) {
                 if (alive) {
                     if (STATS) n_segments++;
@@ -422,6 +438,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
                 }
             }
             if (STATS) sub_cycles[2] += __builtin_readcyclecounter() - t_part;
+            RT_REGION("select");
         }
         if (STATS) {
             const unsigned long long t_end = __builtin_readcyclecounter();

@@ -438,3 +438,144 @@ def statistically_equal(img, mean, var, n, quad_err=None, k_pixel=5.5, k_image=4
         if (np.abs(got - want) > k_image * s + 0.25 * floor).any():
             return f"{what}: off by {np.abs(got - want).max():.5f}, sigma {s.max():.5f}"
     return None
+
+
+# ---------------------------------------------------------------- the widened path: media, motion, checker
+# Scenes the YAML schema cannot express (load.rs builds stationary spheres and solid colours only): a base scene is
+# loaded from YAML and its arrays are then edited, the way the example generator fills them.  `ra` is the product's
+# Python binding (host side only: no GPU is needed to build a description); the oracle takes the same arrays through
+# RefScene.from_desc with a camera of its own.
+WIDE_CAM = dict(frm=(0.0, 0.0, 5.0), to=(0.0, 0.0, 0.0), fov=30.0)
+
+
+def _wide_base(ra, tmp_path, name, background, surface_yaml, aspect):
+    g = WIDE_CAM
+    text = (camera_text(g["frm"], g["to"], g["fov"])
+            + f"scene:\n  background: [{background[0]}, {background[1]}, {background[2]}]\n  surfaces:\n" + surface_yaml)
+    p = tmp_path / f"{name}.yaml"
+    p.write_text(text)
+    return ra.load_scene(str(p), aspect)
+
+
+def wide_camera_params(aspect):
+    g = WIDE_CAM
+    return [g["fov"], aspect, *g["frm"], *g["to"], 0.0, 0.0, 0.0]
+
+
+# ConstantMedium::hit (surfaces.rs:611-651): the free path is -ln(U) / density, and the ray scatters inside the boundary
+# iff that is at most the distance inside, (t_out - t_in) * |d|.  A sphere of BLACK isotropic smoke (albedo 0: a
+# scattered path carries nothing from there on) under the uniform sky therefore shows
+#     E[sample] = L * exp(-density * chord),  chord = 2 sqrt(R^2 - b^2),  b = the ray's distance from the centre.
+SMOKE = dict(radius=1.0, density=0.8)
+
+
+def smoke_ball_desc(ra, tmp_path, aspect=1.0):
+    base = _wide_base(ra, tmp_path, "smoke", L_SKY,
+                      f"    - type: sphere\n      radius: {SMOKE['radius']}\n      position: [0, 0, 0]\n"
+                      "      material: {type: lambertian, albedo: [0, 0, 0]}\n", aspect)
+    mats = base.materials.copy()
+    mats["kind"][0] = ra.RT_MAT_ISOTROPIC
+    media = np.zeros(1, ra.api.MEDIUM_DTYPE)
+    media[0] = (ra.RT_SURF_SPHERE, 0, 1, 0, SMOKE["density"])
+    surfaces = np.array([(ra.RT_SURF_MEDIUM, 0)], dtype=ra.api.SURFACE_DTYPE)  # the boundary sphere itself is not a surface
+    return ra.SceneDesc.from_arrays(mats, base.spheres, base.triangles, base.quads, surfaces, base.background, base.camera,
+                                    media=media)
+
+
+def smoke_ball_expected(w, h, sub=8):
+    """(mean[h, w, 3], var[h, w, 3]) of one sample per pixel."""
+    g = WIDE_CAM
+    o, d = camera_rays(g["frm"], g["to"], g["fov"], w / h, w, h, sub=sub)
+    ud = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    b2 = (o @ o) - (ud @ o) ** 2
+    chord = 2.0 * np.sqrt(np.maximum(SMOKE["radius"] ** 2 - b2, 0.0))
+    p = np.exp(-SMOKE["density"] * chord)  # P(the ray makes it through)
+    sky = np.asarray(L_SKY)
+    mean = p.mean(axis=(2, 3))[..., None] * sky
+    var = np.maximum((p.mean(axis=(2, 3))[..., None] * sky * sky) - mean * mean, 0.0)
+    return mean, var
+
+
+# Sphere::moving / Sphere::center (surfaces.rs:43-54): the centre at ray time t is c0 + t (c1 - c0), and the camera
+# draws t uniformly in [0, 1) (camera.rs:80).  An EMISSIVE moving sphere over a black sky: a sample is the sphere's
+# colour iff the ray meets the sphere where it is at the ray's time, so
+#     E[sample] = colour * |{t in [0, 1) : dist(ray, c(t)) < r}|   — the roots of a quadratic in t.
+MOVER = dict(c0=(-0.8, -0.1, 0.0), c1=(0.8, 0.3, 0.0), r=0.4, colour=(0.9, 0.6, 0.2))
+
+
+def moving_light_desc(ra, tmp_path, aspect=1.0):
+    m = MOVER
+    base = _wide_base(ra, tmp_path, "mover", (0, 0, 0),
+                      f"    - type: sphere\n      radius: {m['r']}\n      position: [{m['c0'][0]}, {m['c0'][1]}, {m['c0'][2]}]\n"
+                      f"      material: {{type: diffuseLight, albedo: [{m['colour'][0]}, {m['colour'][1]}, {m['colour'][2]}]}}\n", aspect)
+    spheres = base.spheres.copy()
+    spheres["moving"][0] = 1
+    spheres["center1"][0] = m["c1"]
+    return ra.SceneDesc.from_arrays(base.materials, spheres, base.triangles, base.quads, base.surfaces, base.background,
+                                    base.camera)
+
+
+def moving_light_expected(w, h, sub=6):
+    g, m = WIDE_CAM, MOVER
+    o, d = camera_rays(g["frm"], g["to"], g["fov"], w / h, w, h, sub=sub)
+    ud = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    c0, dc = np.asarray(m["c0"]) - o, np.asarray(m["c1"]) - np.asarray(m["c0"])
+    w0 = c0 - (ud @ c0)[..., None] * ud          # (c(t) - o) perpendicular to the ray = w0 + t w1
+    w1 = dc - (ud @ dc)[..., None] * ud
+    qa, qb, qc = (w1 * w1).sum(-1), (w0 * w1).sum(-1), (w0 * w0).sum(-1) - m["r"] ** 2
+    disc = qb * qb - qa * qc
+    root = np.sqrt(np.maximum(disc, 0.0))
+    t_lo, t_hi = (-qb - root) / qa, (-qb + root) / qa
+    frac = np.where(disc > 0, np.clip(t_hi, 0, 1) - np.clip(t_lo, 0, 1), 0.0)
+    frac = frac.mean(axis=(2, 3))
+    col = np.asarray(m["colour"])
+    mean = frac[..., None] * col
+    var = np.maximum(frac[..., None] * col * col - mean * mean, 0.0)
+    return mean, var
+
+
+# Checker::color_at (material.rs:237-247): even iff floor(x / s) + floor(y / s) + floor(z / s) is even, s the texture's
+# scale.  A Lambertian checker PLANE under the uniform sky is a furnace: every sample is colour(hit point) * L exactly.
+CHECKER = dict(scale=0.7, even=(0.9, 0.9, 0.9), odd=(0.2, 0.3, 0.1), frm=(0.4, 2.0, 5.0), y=-0.35)
+
+
+def checker_plane_desc(ra, tmp_path, aspect=1.0):
+    c = CHECKER
+    g = dict(WIDE_CAM, frm=c["frm"])
+    text = (camera_text(g["frm"], g["to"], g["fov"])
+            + f"scene:\n  background: [{L_SKY[0]}, {L_SKY[1]}, {L_SKY[2]}]\n  surfaces:\n"
+            + f"    - type: quad\n      position: [-40, {c['y']}, -40]\n      sides: [[0, 0, 80], [80, 0, 0]]\n"
+            + f"      material: {{type: lambertian, albedo: [{c['even'][0]}, {c['even'][1]}, {c['even'][2]}]}}\n")
+    p = tmp_path / "checker.yaml"
+    p.write_text(text)
+    base = ra.load_scene(str(p), aspect)
+    mats = base.materials.copy()
+    mats["texture"][0] = ra.RT_TEX_CHECKER
+    mats["albedo2"][0] = c["odd"]
+    mats["tex_scale"][0] = c["scale"]
+    return ra.SceneDesc.from_arrays(mats, base.spheres, base.triangles, base.quads, base.surfaces, base.background, base.camera)
+
+
+def checker_camera_params(aspect):
+    return [WIDE_CAM["fov"], aspect, *CHECKER["frm"], *WIDE_CAM["to"], 0.0, 0.0, 0.0]
+
+
+def checker_plane_expected(w, h):
+    """(colour[h, w, 3], safe[h, w]): `safe` = the pixel's whole jitter window sees the plane inside one cell."""
+    c = CHECKER
+    o, d = camera_rays(c["frm"], WIDE_CAM["to"], WIDE_CAM["fov"], w / h, w, h, sub=3, edges=True)
+    down = d[..., 1] < -1e-9
+    t = np.where(down, (c["y"] - o[1]) / np.where(down, d[..., 1], -1.0), 0.0)
+    p = o + t[..., None] * d
+    s = p / c["scale"]
+    s[..., 1] = c["y"] / c["scale"]  # the plane's own y, exactly
+    cell = np.floor(s).astype(np.int64)
+    parity = cell.sum(-1) % 2
+    f = s - np.floor(s)
+    inside = down & (np.abs(p[..., 0]) < 39) & (np.abs(p[..., 2]) < 39)
+    for a in (0, 2):
+        inside &= (f[..., a] > 0.06) & (f[..., a] < 0.94)
+    same = (cell[..., 0].max(axis=(2, 3)) == cell[..., 0].min(axis=(2, 3))) & (cell[..., 2].max(axis=(2, 3)) == cell[..., 2].min(axis=(2, 3)))
+    safe = inside.all(axis=(2, 3)) & same
+    colour = np.where(parity[:, :, 1, 1, None] == 0, np.asarray(c["even"]), np.asarray(c["odd"])) * np.asarray(L_SKY)
+    return colour, safe

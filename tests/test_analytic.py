@@ -188,3 +188,50 @@ def test_glass_pane_refracts_by_snell(ref, tmp_path, side, sampler):
     for wrong in (1.0, 1.0 / g["ior"]):
         mean, var, _, qe = A.glass_pane_expected(dict(g, ior=wrong), w, h, "cells")
         assert A.statistically_equal(img / n, mean, var, n, qe) is not None, wrong
+
+
+# ---- the widened path: constant media, moving spheres, the checker texture
+def test_smoke_ball_transmits_exp_of_minus_density_times_chord(ra, ref, tmp_path):
+    """ConstantMedium::hit's free path (surfaces.rs:611-651): a ball of black smoke lets through exp(-density * chord)."""
+    w = h = 40
+    sn = 24
+    n = sn * sn
+    desc = A.smoke_ball_desc(ra, tmp_path)
+    mean, var = A.smoke_ball_expected(w, h)
+    assert mean[h // 2, w // 2, 0] < 0.25 * SKY[0] and np.allclose(mean[0, 0], SKY)  # e^-1.6 through the middle, sky at the corner
+    for sampler in (0, 1):
+        img, _ = ref.RefScene.from_desc(desc, A.wide_camera_params(1.0)).render(w, h, sn, threads=8, sampler=sampler)
+        assert A.statistically_equal(img / n, mean, var, n) is None, sampler
+    # teeth: another density does not fit
+    keep = dict(A.SMOKE)
+    try:
+        A.SMOKE["density"] = 0.6
+        wrong, wvar = A.smoke_ball_expected(w, h)
+    finally:
+        A.SMOKE.update(keep)
+    assert A.statistically_equal(img / n, wrong, wvar, n) is not None
+
+
+def test_moving_light_is_seen_for_the_share_of_the_shutter_it_covers(ra, ref, tmp_path):
+    """Sphere::center (surfaces.rs:52-54) and the uniform shutter time (camera.rs:80)."""
+    w = h = 40
+    sn = 24
+    n = sn * sn
+    desc = A.moving_light_desc(ra, tmp_path)
+    mean, var = A.moving_light_expected(w, h)
+    assert 0.2 < mean[..., 0].max() / A.MOVER["colour"][0] < 0.6  # nowhere lit for the whole shutter: the sphere moves 4 radii
+    for sampler in (0, 1):
+        img, _ = ref.RefScene.from_desc(desc, A.wide_camera_params(1.0)).render(w, h, sn, threads=8, sampler=sampler)
+        assert A.statistically_equal(img / n, mean, var, n) is None, sampler
+
+
+def test_checker_plane_pattern(ra, ref, tmp_path):
+    """Checker::color_at (material.rs:237-247) on a Lambertian plane under the uniform sky: colour(p) * L exactly."""
+    w = h = 64
+    sn = 3
+    desc = A.checker_plane_desc(ra, tmp_path)
+    want, safe = A.checker_plane_expected(w, h)
+    assert safe.sum() > 600 and len(np.unique(want[safe][:, 1])) == 2
+    img, _ = ref.RefScene.from_desc(desc, A.checker_camera_params(1.0)).render(w, h, sn, threads=8, sampler=1)
+    img /= sn * sn
+    assert np.allclose(img[safe], want[safe], rtol=1e-9), np.abs(img[safe] - want[safe]).max()

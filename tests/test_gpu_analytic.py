@@ -210,3 +210,55 @@ def test_glass_pane(ra, tmp_path, floor, side, sampler):
     wrong = dict(g, up=not g["up"]) if floor == "black" else dict(g, ior=1.0)
     mean, var, _, qe = A.glass_pane_expected(wrong, w, h, floor)
     assert A.statistically_equal(img, mean, var, n, qe) is not None
+
+
+# ---- the widened path: constant media, moving spheres, the checker texture — closed forms, not the oracle
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_smoke_ball_transmits_exp_of_minus_density_times_chord(ra, tmp_path, sampler):
+    """ConstantMedium::hit's free path (surfaces.rs:611-651) through the MEDIA build of the kernel."""
+    w = h = 40
+    sn = 64
+    n = sn * sn
+    scene = ra.Scene(A.smoke_ball_desc(ra, tmp_path), 0)
+    mean, var = A.smoke_ball_expected(w, h)
+    for kernel in (0, 1, 2):  # the other organisations defer to the persistent kernel for media
+        img, _ = scene.render(w, h, sn, kernel=kernel, sampler=sampler)
+        img = img.astype(np.float64) / n
+        assert A.statistically_equal(img, mean, var, n) is None, kernel
+    scene.close()
+    keep = dict(A.SMOKE)
+    try:
+        A.SMOKE["density"] = 0.72  # teeth at 4096 spp: a density 10 % off does not fit
+        wrong, wvar = A.smoke_ball_expected(w, h)
+    finally:
+        A.SMOKE.update(keep)
+    assert A.statistically_equal(img, wrong, wvar, n) is not None
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_moving_light_is_seen_for_the_share_of_the_shutter_it_covers(ra, tmp_path, sampler):
+    """Sphere::center at the ray's time (surfaces.rs:52-54), the shutter time drawn uniformly (camera.rs:80): the EXT
+    build of the kernel."""
+    w = h = 40
+    sn = 64
+    n = sn * sn
+    scene = ra.Scene(A.moving_light_desc(ra, tmp_path), 0)
+    mean, var = A.moving_light_expected(w, h)
+    img, _ = scene.render(w, h, sn, sampler=sampler)
+    img = img.astype(np.float64) / n
+    assert A.statistically_equal(img, mean, var, n) is None
+    scene.close()
+
+
+def test_checker_plane_pattern(ra, tmp_path):
+    """Checker::color_at (material.rs:237-247) in f64 on the hit point: colour(p) * L exactly, cell by cell."""
+    w = h = 64
+    sn = 8
+    scene = ra.Scene(A.checker_plane_desc(ra, tmp_path), 0)
+    want, safe = A.checker_plane_expected(w, h)
+    assert safe.sum() > 600
+    for sampler in (0, 1):
+        img, _ = scene.render(w, h, sn, sampler=sampler)
+        img = img.astype(np.float64) / (sn * sn)
+        assert np.allclose(img[safe], want[safe], rtol=F32[0]), np.abs(img[safe] - want[safe]).max()
+    scene.close()
