@@ -104,7 +104,8 @@ class FramePipeline:
 def handout_groups(strata: int, tail_chunks: int = 4) -> int:
     """Chunks per tile of the persistent kernel's guided hand-out (render_persistent.hip: five phases of shrinking
     chunks — 32 strata first for frames of 512 strata and more, else 16, then halving down to 2; a phase leaves
-    four of its chunks' worth — one in scenes without a tree —, at most half of the rest, to the finer ones)."""
+    four of its chunks' worth — eight with a tree of up to 18 levels, one in scenes without a tree —, at most half
+    of the rest, to the finer ones)."""
     first = 32 if strata >= 512 else 16
     done = groups = 0
     for p in range(5):
@@ -456,7 +457,8 @@ def main() -> None:
         hbm_bytes = 12.0 * w * h + 12.0 * my_samples + 216.0 * seg_per_sample * my_samples
     else:
         tiles = ((w + 7) // 8) * ((h + 7) // 8)
-        hbm_bytes = 36.0 * w * h + 768.0 * tiles * handout_groups(my_samples // (w * h), 4 if info.render_nodes else 1)
+        tail = (8 if info.render_depth <= 18 else 4) if info.render_nodes else 1  # render_persistent.hip: tail_chunks
+        hbm_bytes = 36.0 * w * h + 768.0 * tiles * handout_groups(my_samples // (w * h), tail)
 
     if rank == 0:
         workload = (f"scenes/{args.scene}.yaml {w}x{h} {sn * sn} spp, max_depth 40, "

@@ -583,7 +583,11 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // takes several times the mean), but never more than half of what is left; the last phase takes the rest.
     // Without a tree the chunks cost much the same and the samples are cheap (40-50 Gsamples/s): there the small
     // chunks' own overhead shows, and one chunk's worth per phase is enough.
-    const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K"))) : (sc.has_tree ? 4u : 1u);
+    // With a tree: four chunks' worth, eight for the small trees (up to 18 levels) whose scenes run at six waves per
+    // SIMD with short node trips — there the finer tail pays more (measured on the six-wave kernel, RT_TAIL_K 4 / 8:
+    // teapot.yaml 6450 / 6605, dual.yaml 6605 / 6815 Msamples/s; lucy.yaml 13580 / 13500, cornell_lucy.yaml 4401 / 4396).
+    const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K")))
+                                                     : (sc.has_tree ? (tree_depth <= 18u ? 8u : 4u) : 1u);
     // frames of 512 strata and more start with chunks twice as large (+1 %: fewer flushes, longer stays on a tile)
     const uint32_t first_chunk = plan.my_strata >= 512u ? 2u * kChunkStrata : kChunkStrata;
     uint32_t done = 0, groups = 0;
