@@ -130,7 +130,7 @@ def cache_bytes_per_sample(st) -> float:
     return (st.node_visits * 64 + st.tri_tests * 84 + st.sphere_tests * 16 + st.quad_tests * 72) / n
 
 
-PMC_PROFILE = os.path.join("profiles", "r2_final_pmc.json")
+PMC_PROFILE = os.path.join("profiles", "r3_final_pmc.json")
 
 
 def kernel_sources_sha() -> str:

@@ -2,7 +2,7 @@
 # Copies what tools/final_round.sh TAG left under gpurun_out/ into profiles/ under the round's names, and writes the
 # PMC record bench.py reads.   usage: tools/publish_profiles.sh TAG COMMIT [ROUND]    (in the build container)
 set -eu
-TAG=$1; COMMIT=$2; R=${3:-r2}
+TAG=$1; COMMIT=$2; R=${3:-r3}
 F=gpurun_out/final_$TAG; P=gpurun_out/prof_$TAG
 cp $P/kernel_stats.csv profiles/${R}_final_lucy1080p_1024spp_kernel_stats.csv
 cp $P/pmc_summary.txt profiles/${R}_final_lucy1080p_1024spp_pmc.txt
