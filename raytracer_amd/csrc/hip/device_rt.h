@@ -30,7 +30,11 @@ __device__ __forceinline__ void rng_init(Rng& r, uint64_t seed, uint32_t pixel, 
 }
 __device__ __forceinline__ uint32_t rng_next(Rng& r) {
     uint64_t old = r.s;
-    r.s = old * 6364136223846793005ull + 1442695040888963407ull;
+    // (the increment made where it is used, in scalar registers: as a plain literal it was hoisted out of the render
+    // loop into a vector-register pair and, in the tightest builds, spilled to scratch and reloaded at every draw)
+    uint64_t inc = 1442695040888963407ull;
+    asm volatile("" : "+s"(inc));
+    r.s = old * 6364136223846793005ull + inc;
     uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
     uint32_t rot = (uint32_t)(old >> 59);
     return (xs >> rot) | (xs << ((32u - rot) & 31u));

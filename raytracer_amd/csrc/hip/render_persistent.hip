@@ -124,16 +124,27 @@ constexpr uint32_t kGenLens = 5, kGenTime = 7;  // first word of the lens sample
 constexpr int kStageShade = kTraversalDone;
 constexpr int kStageIdle = 0x7ffffffe;
 
+// Pointers that say where they point.  The waves' tile sums and sample batches live in LDS and the accumulator in
+// device memory, and the code says so: as generic pointers the two ends of the "tile sums or accumulator" choice merged
+// into one flat atomic on a selected 64-bit address, the LDS aperture's high word sat in two vector registers for the
+// whole kernel (the six-wave build then spilled the path's throughput), and the called functions took 64-bit pointers.
+typedef __attribute__((address_space(3))) float* LdsFloats;
+typedef __attribute__((address_space(1))) float* DeviceFloats;
+__device__ __forceinline__ uint32_t lds_offset(LdsFloats p) { return (uint32_t)(uintptr_t)p; }
+__device__ __forceinline__ LdsFloats lds_floats(uint32_t offset) { return (LdsFloats)(uintptr_t)offset; }
+__device__ __forceinline__ void add_to(LdsFloats p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void add_to(DeviceFloats p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Adds the wave's LDS tile sums into the tile-planar accumulator (one 256-byte run per component) and clears
 // them.  Called by all 64 lanes.
-__device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc, uint32_t tile, uint32_t lane) {
+__device__ __forceinline__ void flush_tile(float* acc, LdsFloats wacc, uint32_t tile, uint32_t lane) {
     if (tile == 0xffffffffu) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float* g = acc + (size_t)tile * 192u + lane;
+    DeviceFloats g = (DeviceFloats)acc + (size_t)tile * 192u + lane;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = wacc[64 * c + lane];
-        if (v != 0.f) atomicAdd(g + 64 * c, v);
+        if (v != 0.f) add_to(g + 64 * c, v);
         wacc[64 * c + lane] = 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -145,7 +156,8 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ acc, float* wacc,
 struct ChunkOfWork {
     uint32_t tile, first, total;
 };
-__device__ __attribute__((noinline)) ChunkOfWork next_chunk(const void* kernarg, float* wacc, uint32_t acc_tile) {
+__device__ __attribute__((noinline)) ChunkOfWork next_chunk(const void* kernarg, uint32_t wacc_offset, uint32_t acc_tile) {
+    const LdsFloats wacc = lds_floats(wacc_offset);
     const uintptr_t ka = uniform_address(kernarg);
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t c = 0;
@@ -179,8 +191,9 @@ __device__ __attribute__((noinline)) ChunkOfWork next_chunk(const void* kernarg,
 // drawing pixel l's — into the wave's LDS batch.  Out of line: it runs once per 64 samples, and inlined its
 // registers count against every stage of the kernel.
 template <bool DIRECT, bool EXT>
-__device__ __attribute__((noinline)) void draw_batch(const void* kernarg, float* wgen, uint32_t tile, uint32_t local_stratum,
+__device__ __attribute__((noinline)) void draw_batch(const void* kernarg, uint32_t wgen_offset, uint32_t tile, uint32_t local_stratum,
                                                     bool has_lens) {
+    const LdsFloats wgen = lds_floats(wgen_offset);
     // (the kernarg segment's address is the kernel's to know — in a called function the intrinsic yields null — and
     // arrives in vector registers like every argument: made scalar again for the scalar loads)
     const uintptr_t ka = uniform_address(kernarg);
@@ -214,6 +227,12 @@ constexpr int waves_per_simd(bool ext, bool media, int tree, bool noise, bool si
     return tree == 4 ? RT_EXT_NOTREE_WAVES : (tree != 0 ? RT_EXT_PLAIN_WAVES : RT_EXT_WAVES);
 }
 
+// A wave-uniform number the compiler knows nothing about any more (no instruction: an empty asm on its scalar register).
+__device__ __forceinline__ int forget_uniform(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 template <bool STATS, bool DIRECT, bool EXT, bool MEDIA, int TREE, bool NOISE = true, bool SIX = false>
 __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX)) void render_persistent_kernel(DevScene sc, DevRenderParams rp, PersistentPlan plan,
                                                                    float* __restrict__ acc,
@@ -229,8 +248,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
     const SplitStack deep_stack{lds_stack + threadIdx.x};
     for (uint32_t i = threadIdx.x; i < sc.n_loose * kLooseRecQuads; i += kBlock) lds_loose[i] = sc.loose_rec[i];
     // radiance sums of the tile this wave's current chunk belongs to (3 x 64 floats per wave)
-    float* wacc = lds_acc + (threadIdx.x >> 6) * 192;
-    float* wgen = lds_acc + (kBlock / 64) * 192 + (threadIdx.x >> 6) * plan.gen_words * 64u;
+    const LdsFloats wacc = (LdsFloats)lds_acc + (threadIdx.x >> 6) * 192;
+    const LdsFloats wgen = (LdsFloats)lds_acc + (kBlock / 64) * 192 + (threadIdx.x >> 6) * plan.gen_words * 64u;
     wacc[threadIdx.x & 63u] = 0.f, wacc[64 + (threadIdx.x & 63u)] = 0.f, wacc[128 + (threadIdx.x & 63u)] = 0.f;
     uint32_t acc_tile = 0xffffffffu;  // wave-uniform
     __syncthreads();
@@ -281,10 +300,24 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
         const int n_shade = __popcll(m_shade), n_leaf = __popcll(m_leaf), n_node = __popcll(m_node);
         if ((n_shade | n_leaf | n_node) == 0) break;  // every lane idle: no paths in flight, no work left
 
-        // TREE == 4: a scene without a render tree (every primitive loose) — no node or leaf stage is compiled in
-        const bool run_shade = TREE == 4 || n_shade >= plan.shade_threshold || (n_node | n_leaf) == 0;
         if (STATS) t_begin = __builtin_readcyclecounter();
-        if (!run_shade && n_node * plan.node_bias >= n_leaf * 4) {
+        // Which stage runs: the shade stage (2) once shade_threshold lanes wait in it or nothing else can run, otherwise
+        // the node stage (0) or the leaf stage (1), whichever has more lanes (node_bias weighs them).  TREE == 4: a scene
+        // without a render tree (every primitive loose) — no node or leaf stage is compiled in.
+        // The stage is a number, forgotten and compared again before each stage's code: three plain `if`s in a row.  (As
+        // an if / else-if / else chain, the structuriser threads every per-lane value the stages change through the join
+        // blocks it adds, and the copies it leaves there — the closest-hit record's six words back and forth, in every
+        // trip, the node trips that do not touch it included — are never coalesced: 13 moves per trip.)
+        int stage = 2;
+        if (TREE != 4)
+            asm volatile(  // on the scalar unit, and opaque to the compiler like forget_uniform's
+                "s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 0, 1\n\t"
+                "s_cmp_ge_i32 %3, %4\n\ts_cselect_b32 %0, 2, %0\n\t"
+                "s_cmp_eq_u32 %5, 0\n\ts_cselect_b32 %0, 2, %0"
+                : "=&s"(stage)
+                : "s"(n_node * plan.node_bias), "s"(n_leaf * 4), "s"(n_shade), "s"(plan.shade_threshold), "s"(n_node | n_leaf)
+                : "scc");
+        if (stage == 0) {
             if (STATS) trips[0]++, lanes_on[0] += n_node, stage_run = 0;
             if (STATS && exhausted) drain_trips[0]++, drain_lanes[0] += n_node;
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent
@@ -301,7 +334,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
                     if (node >= 0 && node < kStageIdle) node = node_step<STATS>(sc, sr, 0.001f, best.h.t, node, stack, sp, st);
             }
             RT_REGION("select");
-        } else if (!run_shade) {
+        }
+        stage = forget_uniform(stage);
+        if (stage == 1) {
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
             RT_REGION("leaf");
@@ -309,7 +344,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
                 leaf_step<STATS, EXT, TREE>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = (SIX && sp > (int)kLdsStackCap) ? stack_pop(deep_stack, sp) : stack_pop(stack, sp);
             }
-        } else {
+        }
+        stage = forget_uniform(stage);
+        if (stage == 2) {
             if (STATS) trips[2]++, lanes_on[2] += n_shade, stage_run = 2;
             if (STATS && exhausted) drain_trips[2]++, drain_lanes[2] += n_shade;
             RT_REGION("shade.bounce");
@@ -352,15 +389,15 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
                 }
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
-                    float* a = acc_now + (size_t)(pix >> 6) * 192u + (pix & 63u);
                     if ((pix >> 6) == acc_tile) {  // the wave's current tile: sum in LDS, flushed once per chunk
-                        atomicAdd(wacc + (pix & 63u), lsum.x);
-                        atomicAdd(wacc + 64 + (pix & 63u), lsum.y);
-                        atomicAdd(wacc + 128 + (pix & 63u), lsum.z);
+                        add_to(wacc + (pix & 63u), lsum.x);
+                        add_to(wacc + 64 + (pix & 63u), lsum.y);
+                        add_to(wacc + 128 + (pix & 63u), lsum.z);
                     } else {  // a path that outlived its chunk
-                        atomicAdd(a, lsum.x);
-                        atomicAdd(a + 64, lsum.y);
-                        atomicAdd(a + 128, lsum.z);
+                        const DeviceFloats a = (DeviceFloats)acc_now + (size_t)(pix >> 6) * 192u + (pix & 63u);
+                        add_to(a, lsum.x);
+                        add_to(a + 64, lsum.y);
+                        add_to(a + 128, lsum.z);
                     }
                 }
             }
@@ -373,7 +410,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
             unsigned long long need = __ballot(mine && !alive);
             while (need != 0ull && !exhausted) {
                 if (next_j >= chunk_total) {
-                    const ChunkOfWork ch = next_chunk((const void*)__builtin_amdgcn_kernarg_segment_ptr(), wacc, acc_tile);
+                    const ChunkOfWork ch = next_chunk((const void*)__builtin_amdgcn_kernarg_segment_ptr(), lds_offset(wacc), acc_tile);
                     chunk_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.total);
                     if (chunk_total == 0u) {
                         exhausted = true;
@@ -388,7 +425,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
                 }
                 if (gen_j != (next_j & ~63u)) {  // wave-uniform: draw the batch next_j starts
                     gen_j = next_j & ~63u;
-                    draw_batch<DIRECT, EXT>((const void*)__builtin_amdgcn_kernarg_segment_ptr(), wgen, chunk_tile,
+                    draw_batch<DIRECT, EXT>((const void*)__builtin_amdgcn_kernarg_segment_ptr(), lds_offset(wgen), chunk_tile,
                                             chunk_first + (gen_j >> 6), has_lens);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
