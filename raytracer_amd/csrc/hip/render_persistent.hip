@@ -384,8 +384,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
                         light = again && best.h.slot > kMediumSlot && (emitted.x != 0.f || emitted.y != 0.f || emitted.z != 0.f);
                     } while (again && alive);
                 } else {
-                    alive = shade_bounce<DIRECT, EXT, NOISE>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum, depth,
-                                                      max_depth);
+                    alive = shade_bounce<DIRECT, EXT, NOISE, TREE == 1>(ss, lds_loose, ray, best.h, best.meta, 0.001f, rng, thr, lsum,
+                                                                 depth, max_depth);
                 }
                 if (!alive && (lsum.x != 0.f || lsum.y != 0.f || lsum.z != 0.f)) {
                     // tile-planar accumulator: the lanes of a wave add into one 256-byte run per component
