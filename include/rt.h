@@ -109,6 +109,23 @@ typedef struct rt_surface_ref {
     int32_t index; /* into spheres / triangles / quads */
 } rt_surface_ref;
 
+/* A tree inside the tree: Surface::Bvh (surfaces.rs:374), a member of its parent's BVH that is a BVH itself — the
+ * small spheres of one-weekend beside the ground sphere (example.rs:96-139), make_box's one leaf of six quads
+ * (surfaces.rs:542-591), final-scene's tree of boxes and its turned cluster of spheres (example.rs:487-498, 553-570).
+ * Hits do not depend on the nesting; what does is the in-order leaf sequence, i.e. which of two surfaces wins an exact
+ * equal-t tie (bvh.rs:272-273, 308): the parent's build sees the group as ONE item with ONE box, and the group's own
+ * tree is built over its members alone.  Instancing wrappers around a group (Rotated / Translated, surfaces.rs:461-540)
+ * are baked into the members' coordinates; what they leave behind is the group's box in its parent's build (`box`)
+ * and, since the reference builds a wrapped group's tree in the group's own space, the members' boxes there
+ * (rt_scene_desc.surface_build_box). */
+typedef struct rt_bvh_group {
+    int32_t parent;  /* enclosing group (listed before this one), -1 = the scene's own list (scene/mod.rs:31) */
+    int32_t leaf;    /* non-zero: Bvh::new_leaf (bvh.rs:63-68) — one leaf, the members in their listing order */
+    double box[6];   /* lo.xyz hi.xyz of the group as its parent's build sees it (Bvh::bounding_box, through
+                        Aabb::rotate / Aabb::translate where the reference wraps the group, trace.rs:185-211);
+                        box[0] > box[3]: none given — the union of the members' boxes */
+} rt_bvh_group;
+
 /* camera.rs:11-18 after Camera::new (camera.rs:43-74) */
 typedef struct rt_camera {
     double origin[3], lower_left[3], horizontal[3], vertical[3];
@@ -140,6 +157,14 @@ typedef struct rt_scene_desc {
     size_t n_images;
     const rt_medium* media;  /* constant media (RT_SURF_MEDIUM surfaces index this) */
     size_t n_media;
+    /* nesting of the reference-topology tree (null / 0: none — every scene file; the example scenes nest) */
+    const rt_bvh_group* groups;
+    size_t n_groups;
+    const int32_t* surface_group;    /* n_surfaces entries: the group a surface is a member of, -1 = the scene's own
+                                        list; the surfaces of a group, its sub-groups' included, are contiguous */
+    const double* surface_build_box; /* 6 per surface or null: lo.xyz hi.xyz of the surface in its group's build where
+                                        that is not its own bounding box (a member of a rotated group: the box in the
+                                        group's own space); lo.x > hi.x: its own bounding box */
 } rt_scene_desc;
 
 /* ---- host-side loader: replaces scene::load_scene (load.rs:39-160) ---- */

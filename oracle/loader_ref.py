@@ -371,6 +371,26 @@ def _turned_box(a, b, degrees, offset):
     return out
 
 
+def _turned_box_bounds(a, b, degrees, offset):
+    """Bounding box of Translated::new(Rotated::new(make_box(a, b), +y, degrees), offset) — what the scene's own BVH
+    build sees of the box: the leaf's bound (the merge of the quads' padded boxes), its eight corners turned about its
+    midpoint (Aabb::rotate, trace.rs:191-211), shifted (Aabb::translate, trace.rs:185-189)."""
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for q, u, v in _make_box(np.asarray(a, float), np.asarray(b, float)):
+        far = q + u + v
+        blo, bhi = _pad_box(np.minimum(q, far), np.maximum(q, far))
+        lo, hi = np.minimum(lo, blo), np.maximum(hi, bhi)
+    delta = hi - lo
+    mid = lo + 0.5 * delta
+    rot = quat_rotation(np.array([0.0, 1.0, 0.0]), math.radians(degrees))
+    mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
+    for ii in range(8):
+        corner = lo + np.array([float(ii & 1), float((ii >> 1) & 1), float((ii >> 2) & 1)]) * delta
+        r = quat_rotate_point(rot, mid, corner)
+        mn, mx = np.minimum(mn, r), np.maximum(mx, r)
+    return np.concatenate([mn + offset, mx + offset])
+
+
 def example_scene(name):
     """-> dict(camera=[fov, from, towards, aperture, focus or None], background, surfaces=[...], media=[...]).
     A surface is ("sphere", centre, radius, material) or ("quad", q, u, v, material); a medium is
@@ -401,11 +421,16 @@ def example_scene(name):
                     ("quad", V(0, 0, 555), V(555, 0, 0), V(0, 555, 0), white)]
         box1 = _turned_box((0.0, 0.001, 0.0), (165.0, 333.0, 165.0), 15.0, V(265, 0, 295))
         box2 = _turned_box((0.0, 0.001, 0.0), (165.0, 165.0, 165.0), -18.0, V(130, 0, 65))
-        media = []
+        media, groups, surface_group = [], [], [-1] * 6
         if smoke:  # ConstantMedium::new(box, 0.01, colour), example.rs:387-398
             media = [(box1, 0.01, (0.0, 0.0, 0.0)), (box2, 0.01, (1.0, 1.0, 1.0))]
         else:
             surfaces += [("quad", q, u, v, white) for q, u, v in box1 + box2]
+            # each box is a Surface::Bvh of ONE leaf (make_box -> Bvh::new_leaf) wrapped and added to the scene's list
+            # (example.rs:310-326): groups (parent, is one leaf, box in the scene's build), a group per surface
+            groups = [(-1, 1, _turned_box_bounds((0.0, 0.001, 0.0), (165.0, 333.0, 165.0), 15.0, V(265, 0, 295))),
+                      (-1, 1, _turned_box_bounds((0.0, 0.001, 0.0), (165.0, 165.0, 165.0), -18.0, V(130, 0, 65)))]
+            surface_group += [0] * 6 + [1] * 6
         return dict(camera=[40.0, (278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 0.0, None], background=(0.0, 0.0, 0.0),
-                    surfaces=surfaces, media=media)
+                    surfaces=surfaces, media=media, groups=groups, surface_group=surface_group)
     raise ValueError(f"{name}: not one of the examples that draw no random numbers")

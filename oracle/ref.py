@@ -28,6 +28,8 @@ def lib():
         L.ref_scene_create_ext.argtypes = [dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp, C.c_size_t, dp,
                                            C.c_size_t, dp, dp, C.c_int, dp, dp, dp, dp, C.c_size_t, dp, dp, C.c_size_t,
                                            dp, C.c_size_t]
+        L.ref_scene_create_nested.restype = vp
+        L.ref_scene_create_nested.argtypes = L.ref_scene_create_ext.argtypes + [dp, C.c_size_t, dp, dp]
         L.ref_scene_destroy.argtypes = [vp]
         L.ref_leaf_order.argtypes = [vp, dp, dp]
         L.ref_camera.argtypes = [vp, dp]
@@ -80,10 +82,17 @@ class RefScene:
             ib = np.ascontiguousarray(ext["image_bytes"], dtype=np.uint8)
             idm = np.ascontiguousarray(ext["image_dims"], dtype=np.int64)
             md = _d(ext["media"])
-            self._keep = (me, se, pv, pp, ib, idm, md)
-            self._h = lib().ref_scene_create_ext(_p(m), len(m), _p(s), len(s), _p(t), len(t), _p(q), len(q), _p(sf),
-                                                 len(sf), _p(bg), _p(cam), 1 if use_bvh else 0, _p(me), _p(se), _p(pv),
-                                                 _p(pp), len(pp), _p(ib), _p(idm), len(idm), _p(md), len(md))
+            # nesting of the tree (rt_bvh_group): groups n x 8 doubles, a group per surface, build boxes n x 6 or None
+            gr = _d(ext["groups"]).reshape(-1, 8) if ext.get("groups") is not None else np.zeros((0, 8))
+            sg = np.ascontiguousarray(ext["surface_group"], dtype=np.int32) if len(gr) else np.zeros(0, np.int32)
+            bb = _d(ext["surface_build_box"]).reshape(-1, 6) if len(gr) and ext.get("surface_build_box") is not None else None
+            assert not len(gr) or len(sg) == len(sf)
+            self._keep = (me, se, pv, pp, ib, idm, md, gr, sg, bb)
+            self._h = lib().ref_scene_create_nested(_p(m), len(m), _p(s), len(s), _p(t), len(t), _p(q), len(q), _p(sf),
+                                                    len(sf), _p(bg), _p(cam), 1 if use_bvh else 0, _p(me), _p(se), _p(pv),
+                                                    _p(pp), len(pp), _p(ib), _p(idm), len(idm), _p(md), len(md),
+                                                    _p(gr) if len(gr) else None, len(gr), _p(sg) if len(gr) else None,
+                                                    _p(bb) if bb is not None else None)
         if not self._h:
             raise RuntimeError("ref_scene_create failed (bad surface index)")
 
@@ -125,6 +134,11 @@ class RefScene:
             image_dims=np.array(dims, dtype=np.int64).reshape(-1, 3),
             media=np.column_stack([desc.media[k].astype(np.float64) for k in ("boundary", "first", "count", "material",
                                                                                "density")]).reshape(-1, 5))
+        g = desc.groups
+        if len(g):
+            flat.extras["groups"] = np.column_stack([g["parent"].astype(np.float64), g["leaf"].astype(np.float64), g["box"]])
+            flat.extras["surface_group"] = desc.surface_group
+            flat.extras["surface_build_box"] = desc.surface_build_box
         return cls(flat, use_bvh)
 
     def close(self):

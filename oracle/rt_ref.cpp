@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -342,8 +343,17 @@ struct Counters {
     uint64_t box_tests = 0, tri_tests = 0, sphere_tests = 0, quad_tests = 0, segments = 0;
 };
 
+struct BVHNode;
 struct Surface {
-    enum Type { SphereT = 0, TriangleT = 1, QuadT = 2, MediumT = 3 } type;
+    // BvhT: Surface::Bvh (surfaces.rs:374), a tree that is a member of another tree's leaf (example.rs:96-139, 498, 568;
+    // make_box, surfaces.rs:542-591)
+    enum Type { SphereT = 0, TriangleT = 1, QuadT = 2, MediumT = 3, BvhT = 4 } type;
+    std::shared_ptr<BVHNode> sub;  // BvhT
+    // Where the reference wraps a tree in Rotated / Translated it builds that tree in the tree's own space and turns
+    // the ray at run time; the scenes arrive here with the wrappers baked into the members' coordinates, so a member
+    // has two boxes: `box`, what the reference's BUILD sees (its own-space box; for a wrapped tree the turned box,
+    // trace.rs:185-211), and `wbox`, the world-space bound the traversal tests (equal to `box` wherever nothing is wrapped).
+    Aabb wbox;
     int id;  // index in the scene's surface list
     const Material* material;
     // sphere
@@ -389,8 +399,12 @@ struct Surface {
         }
     }
 
+    bool sub_hit(const Ray& ray, Interval iv, Hit& out, Counters& c) const;  // Bvh::hit -> its root (bvh.rs:98-102)
+
     bool hit(const Ray& ray, Interval iv, Hit& out, Counters& c) const {
         switch (type) {
+            case BvhT:
+                return sub_hit(ray, iv, out, c);
             case MediumT:  // evaluated after the surface trace (Scene::media_hit), where the path's RNG is at hand
                 return false;
             case SphereT: {  // surfaces.rs:73-106; the sphere uv (:108-118) only where a texture reads it
@@ -498,6 +512,27 @@ struct BVHNode {
         return true;
     }
 };
+
+bool Surface::sub_hit(const Ray& ray, Interval iv, Hit& out, Counters& c) const { return sub->hit(ray, iv, out, c); }
+
+// After a build over own-space boxes: every node's bound as the world-space bound of what lies below it (a no-op
+// where nothing is wrapped: merging is exact).
+void rebound(BVHNode* n) {
+    if (n->leaf) {
+        n->bound = Aabb::empty();
+        for (Surface& s : n->surfaces) {
+            if (s.type == Surface::BvhT) {
+                rebound(s.sub.get());
+                s.wbox = s.sub->bound;
+            }
+            n->bound = n->bound.merge(s.wbox);
+        }
+        return;
+    }
+    rebound(n->left.get());
+    rebound(n->right.get());
+    n->bound = n->left->bound.merge(n->right->bound);
+}
 
 std::unique_ptr<BVHNode> new_leaf(std::vector<Surface> surfaces) {  // bvh.rs:289-298
     auto n = std::make_unique<BVHNode>();
@@ -701,7 +736,10 @@ void collect_order(const BVHNode* n, std::vector<int32_t>& out, uint32_t depth, 
     if (n->leaf) {
         stats[1]++;                              // leaves
         stats[3] = std::max<uint32_t>(stats[3], (uint32_t)n->surfaces.size());
-        for (const Surface& s : n->surfaces) out.push_back(s.id);
+        for (const Surface& s : n->surfaces) {
+            if (s.type == Surface::BvhT) collect_order(s.sub.get(), out, depth + 1, stats);  // a nested tree, in place
+            else out.push_back(s.id);
+        }
         return;
     }
     collect_order(n->left.get(), out, depth + 1, stats);
@@ -726,12 +764,19 @@ extern "C" {
 //   image_dims  n_images x 3 int64: byte offset into image_bytes, width, height
 //   media       n_media x 5   : boundary type (0 sphere | 2 quads), first, count, material, density; a surface
 //                               row {3, k} places medium k in the surface list
-void* ref_scene_create_ext(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,
-                           const double* triangles, size_t n_tri, const double* quads, size_t n_quad,
-                           const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
-                           int use_bvh, const double* mat_ext, const double* sphere_end, const double* perlin_vec,
-                           const int32_t* perlin_perm, size_t n_perlin, const uint8_t* image_bytes,
-                           const int64_t* image_dims, size_t n_images, const double* media, size_t n_media) {
+// Nesting (null / 0 = none), rt_bvh_group in include/rt.h:
+//   groups             n_groups x 8 : parent (-1 = the scene's own list; listed before its children), leaf (1 =
+//                                     Bvh::new_leaf), box lo.xyz hi.xyz in the parent's build (lo.x > hi.x: the members' union)
+//   surface_group      n_surf int32 : the group a surface is a member of, -1 = the scene's own list
+//   surface_build_box  n_surf x 6   : the surface's box in its group's build where that is not its own (lo.x > hi.x: its own)
+void* ref_scene_create_nested(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,
+                              const double* triangles, size_t n_tri, const double* quads, size_t n_quad,
+                              const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
+                              int use_bvh, const double* mat_ext, const double* sphere_end, const double* perlin_vec,
+                              const int32_t* perlin_perm, size_t n_perlin, const uint8_t* image_bytes,
+                              const int64_t* image_dims, size_t n_images, const double* media, size_t n_media,
+                              const double* groups, size_t n_groups, const int32_t* surface_group,
+                              const double* surface_build_box) {
     auto sc = std::make_unique<Scene>();
     sc->perlin.resize(n_perlin);
     for (size_t k = 0; k < n_perlin; ++k) {
@@ -846,10 +891,74 @@ void* ref_scene_create_ext(const double* materials, size_t n_mat, const double* 
         list.push_back(s);
     }
     sc->n_surfaces = n_surf;
+    for (Surface& s : list) s.wbox = s.box;
+    if (groups && n_groups && surface_group) {
+        // members of every list in the order the reference adds them: a group joins its parent's list where its first
+        // surface stands
+        std::vector<std::vector<int32_t>> members(n_groups + 1);
+        std::vector<char> listed(n_groups, 0);
+        auto parent_of = [&](int32_t g) { return (int32_t)groups[8 * (size_t)g]; };
+        for (size_t g = 0; g < n_groups; ++g)
+            if (parent_of((int32_t)g) < -1 || parent_of((int32_t)g) >= (int32_t)g) return nullptr;
+        for (size_t i = 0; i < n_surf; ++i) {
+            const int32_t g = surface_group[i];
+            if (g < -1 || g >= (int32_t)n_groups) return nullptr;
+            std::vector<int32_t> chain;
+            for (int32_t k = g; k >= 0 && !listed[(size_t)k]; k = parent_of(k)) chain.push_back(k);
+            for (size_t c = chain.size(); c-- > 0;) {
+                listed[(size_t)chain[c]] = 1;
+                members[(size_t)(parent_of(chain[c]) + 1)].push_back(~chain[c]);
+            }
+            members[(size_t)(g + 1)].push_back((int32_t)i);
+        }
+        std::function<std::vector<Surface>(int32_t)> items_of;
+        auto tree_of = [&](int32_t g) {  // Surface::Bvh for group g
+            Surface b{};
+            b.type = Surface::BvhT;
+            b.id = -1;
+            std::vector<Surface> items = items_of(g);
+            b.sub = groups[8 * (size_t)g + 1] != 0.0 ? std::shared_ptr<BVHNode>(new_leaf(std::move(items)))
+                                                      : std::shared_ptr<BVHNode>(build_node(std::move(items)));
+            const double* gb = groups + 8 * (size_t)g + 2;
+            b.box = gb[0] > gb[3] ? b.sub->bound : Aabb{V(gb), V(gb + 3)};  // Bvh::bounding_box = the root's
+            b.wbox = b.box;  // set by rebound
+            return b;
+        };
+        items_of = [&](int32_t g) {
+            std::vector<Surface> items;
+            for (int32_t code : members[(size_t)(g + 1)]) {
+                if (code < 0) {
+                    items.push_back(tree_of(~code));
+                    continue;
+                }
+                Surface s = list[(size_t)code];
+                if (surface_build_box) {
+                    const double* bb = surface_build_box + 6 * (size_t)code;
+                    if (!(bb[0] > bb[3])) s.box = Aabb{V(bb), V(bb + 3)};
+                }
+                items.push_back(s);
+            }
+            return items;
+        };
+        std::vector<Surface> top = items_of(-1);
+        sc->root = use_bvh ? build_node(std::move(top)) : new_leaf(std::move(top));
+        rebound(sc->root.get());
+    } else
     sc->root = use_bvh ? build_node(std::move(list)) : new_leaf(std::move(list));  // scene/mod.rs:60-71
     sc->background = V(background);
     sc->camera = Camera::make(camera[0], camera[1], V(camera + 2), V(camera + 5), camera[8], camera[9] != 0.0, camera[10]);
     return sc.release();
+}
+
+void* ref_scene_create_ext(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,
+                           const double* triangles, size_t n_tri, const double* quads, size_t n_quad,
+                           const int32_t* surfaces, size_t n_surf, const double* background, const double* camera,
+                           int use_bvh, const double* mat_ext, const double* sphere_end, const double* perlin_vec,
+                           const int32_t* perlin_perm, size_t n_perlin, const uint8_t* image_bytes,
+                           const int64_t* image_dims, size_t n_images, const double* media, size_t n_media) {
+    return ref_scene_create_nested(materials, n_mat, spheres, n_sph, triangles, n_tri, quads, n_quad, surfaces, n_surf,
+                                   background, camera, use_bvh, mat_ext, sphere_end, perlin_vec, perlin_perm, n_perlin,
+                                   image_bytes, image_dims, n_images, media, n_media, nullptr, 0, nullptr, nullptr);
 }
 
 void* ref_scene_create(const double* materials, size_t n_mat, const double* spheres, size_t n_sph,

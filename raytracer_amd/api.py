@@ -49,6 +49,10 @@ class RtMedium(C.Structure):
                 ("density", C.c_double)]
 
 
+class RtBvhGroup(C.Structure):
+    _fields_ = [("parent", C.c_int32), ("leaf", C.c_int32), ("box", C.c_double * 6)]
+
+
 class RtImage(C.Structure):
     _fields_ = [("rgb", C.POINTER(C.c_uint8)), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -83,6 +87,8 @@ class RtSceneDesc(C.Structure):
         ("perlin", C.POINTER(RtPerlin)), ("n_perlin", C.c_size_t),
         ("images", C.POINTER(RtImage)), ("n_images", C.c_size_t),
         ("media", C.POINTER(RtMedium)), ("n_media", C.c_size_t),
+        ("groups", C.POINTER(RtBvhGroup)), ("n_groups", C.c_size_t),
+        ("surface_group", C.POINTER(C.c_int32)), ("surface_build_box", C.POINTER(C.c_double)),
     ]
 
 
@@ -117,6 +123,7 @@ TRIANGLE_DTYPE = np.dtype([("v", "<f8", (3, 3)), ("n", "<f8", (3, 3)), ("materia
 QUAD_DTYPE = np.dtype([("q", "<f8", 3), ("u", "<f8", 3), ("v", "<f8", 3), ("normal", "<f8", 3), ("d", "<f8"),
                        ("w", "<f8", 3), ("material", "<i4"), ("_pad", "<i4")])
 SURFACE_DTYPE = np.dtype([("type", "<i4"), ("index", "<i4")])
+GROUP_DTYPE = np.dtype([("parent", "<i4"), ("leaf", "<i4"), ("box", "<f8", 6)])
 
 
 class RtError(RuntimeError):
@@ -222,8 +229,11 @@ class SceneDesc:
     # -- construction from numpy arrays (synthetic scenes in tests)
     @classmethod
     def from_arrays(cls, materials, spheres, triangles, quads, surfaces, background, camera: RtCamera,
-                    use_bvh=True, perlin=None, images=(), media=None) -> "SceneDesc":
-        """`perlin`: array of PERLIN_DTYPE; `images`: sequence of uint8 arrays of shape (h, w, 3)."""
+                    use_bvh=True, perlin=None, images=(), media=None, groups=None, surface_group=None,
+                    surface_build_box=None) -> "SceneDesc":
+        """`perlin`: array of PERLIN_DTYPE; `images`: sequence of uint8 arrays of shape (h, w, 3); `groups`
+        (GROUP_DTYPE), `surface_group` (int32 per surface), `surface_build_box` (6 doubles per surface or None):
+        nesting of the reference-topology tree, rt_bvh_group in include/rt.h."""
         arrs = dict(
             materials=np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE),
             spheres=np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE),
@@ -253,6 +263,17 @@ class SceneDesc:
         arrs["media"] = np.ascontiguousarray(media if media is not None else np.zeros(0, MEDIUM_DTYPE), dtype=MEDIUM_DTYPE)
         d.media = C.cast(arrs["media"].ctypes.data, C.POINTER(RtMedium))
         d.n_media = len(arrs["media"])
+        if groups is not None and len(groups):
+            arrs["groups"] = np.ascontiguousarray(groups, dtype=GROUP_DTYPE)
+            arrs["surface_group"] = np.ascontiguousarray(surface_group, dtype=np.int32)
+            assert len(arrs["surface_group"]) == len(arrs["surfaces"])
+            d.groups = C.cast(arrs["groups"].ctypes.data, C.POINTER(RtBvhGroup))
+            d.n_groups = len(arrs["groups"])
+            d.surface_group = C.cast(arrs["surface_group"].ctypes.data, C.POINTER(C.c_int32))
+            if surface_build_box is not None:
+                arrs["surface_build_box"] = np.ascontiguousarray(surface_build_box, dtype=np.float64).reshape(-1, 6)
+                assert len(arrs["surface_build_box"]) == len(arrs["surfaces"])
+                d.surface_build_box = C.cast(arrs["surface_build_box"].ctypes.data, C.POINTER(C.c_double))
         self = cls(None, arrs)
         self._struct = d
         return self
@@ -268,6 +289,22 @@ class SceneDesc:
     surfaces = property(lambda s: _view(s._struct.surfaces, s._struct.n_surfaces, SURFACE_DTYPE))
     perlin = property(lambda s: _view(s._struct.perlin, s._struct.n_perlin, PERLIN_DTYPE))
     media = property(lambda s: _view(s._struct.media, s._struct.n_media, MEDIUM_DTYPE))
+    groups = property(lambda s: _view(s._struct.groups, s._struct.n_groups, GROUP_DTYPE))
+
+    @property
+    def surface_group(self):
+        """int32 per surface (-1: the scene's own list), or None when the scene does not nest."""
+        st = self._struct
+        if not st.n_groups or not st.surface_group:
+            return None
+        return np.ctypeslib.as_array(st.surface_group, shape=(st.n_surfaces,)).copy()
+
+    @property
+    def surface_build_box(self):
+        st = self._struct
+        if not st.n_groups or not st.surface_build_box:
+            return None
+        return np.ctypeslib.as_array(st.surface_build_box, shape=(st.n_surfaces, 6)).copy()
 
     @property
     def images(self):
@@ -279,7 +316,8 @@ class SceneDesc:
                        else np.zeros((0, 0, 3), np.uint8))
         return out
     background = property(lambda s: np.array(list(s._struct.background)))
-    camera = property(lambda s: s._struct.camera)
+    # (a copy: the struct lives in the library's memory and goes with the description)
+    camera = property(lambda s: RtCamera.from_buffer_copy(s._struct.camera))
     n_surfaces = property(lambda s: int(s._struct.n_surfaces))
     use_bvh = property(lambda s: bool(s._struct.use_bvh))
 

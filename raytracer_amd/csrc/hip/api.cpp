@@ -207,6 +207,7 @@ void validate(const rt_scene_desc& d) {
         if (m.boundary == RT_SURF_QUAD && m.count > 6) throw std::runtime_error("a medium's boundary is one sphere or the (up to six) quads of a box");
     }
     if (d.n_media > kMaxMedia) throw std::runtime_error("too many media (at most " + std::to_string(kMaxMedia) + ")");
+    if (d.n_groups > 0 && (!d.groups || !d.surface_group)) throw std::runtime_error("groups given without surface_group");
     for (size_t i = 0; i < d.n_surfaces; ++i) {
         const rt_surface_ref& s = d.surfaces[i];
         size_t n = s.type == RT_SURF_SPHERE ? d.n_spheres
@@ -300,7 +301,7 @@ void flatten_reference64(rt_scene& s) {
 // the reference-topology tree's figures (rt_scene_info)
 void reference_tree_info(rt_scene& s, size_t n_surfaces) {
     s.info.n_surfaces = n_surfaces;
-    s.info.n_nodes = s.bvh.nodes.size();
+    s.info.n_nodes = s.bvh.ref_nodes ? s.bvh.ref_nodes : s.bvh.nodes.size();
     s.info.n_leaves = s.bvh.n_leaves;
     s.info.max_depth = s.bvh.max_depth;
     s.info.max_leaf_size = s.bvh.max_leaf_size;
@@ -633,12 +634,18 @@ void flatten_render(const rt_scene_desc& d, rt_scene& s) {
             const rt_surface_ref& ref = d.surfaces[s.bvh.order[k]];
             if (ref.type == RT_SURF_TRIANGLE || ref.type == RT_SURF_MEDIUM) continue;  // Triangle::bounding_box is exact
             double* gate = ref.type == RT_SURF_SPHERE ? &s.sphere_gate[6 * ref.index] : &s.quad_gate[6 * ref.index];
-            for (int a = 0; a < 3; ++a) gate[a] = n.box.lo.get(a), gate[3 + a] = n.box.hi.get(a);
+            // (a run of surfaces inside a reference leaf that also holds nested trees: the whole leaf's box)
+            const Aabb& leaf_box = n.gate >= 0 ? s.bvh.nodes[n.gate].box : n.box;
+            for (int a = 0; a < 3; ++a) gate[a] = leaf_box.lo.get(a), gate[3 + a] = leaf_box.hi.get(a);
             // a leaf box that encloses the surface is crossed by every ray that hits the surface: no test needed
+            // (up to the rounding of a baked corner: the six quads of a turned box meet in corners that each quad reaches
+            // by its own sums, q + u + v here, q there — an ulp apart, which is no reason to gate a face by its own box)
             const Aabb tb = true_bounds(d, ref);
             bool encloses = true;
-            for (int a = 0; a < 3; ++a)
-                encloses = encloses && n.box.lo.get(a) <= tb.lo.get(a) && tb.hi.get(a) <= n.box.hi.get(a);
+            for (int a = 0; a < 3; ++a) {
+                const double slack = 1e-9 * (tb.hi.get(a) - tb.lo.get(a));
+                encloses = encloses && leaf_box.lo.get(a) <= tb.lo.get(a) + slack && tb.hi.get(a) - slack <= leaf_box.hi.get(a);
+            }
             if (encloses) gate[0] = -INFINITY;
         }
     }
@@ -1136,7 +1143,7 @@ int rt_primary_hits(rt_scene* scene, uint32_t width, uint32_t height, int precis
             throw std::runtime_error("bad image size");
         if (precision != 32 && precision != 64) throw std::runtime_error("precision must be 32 or 64");
         // the f64 kernel's depth-first walk keeps at most one entry per level plus one on its private stack
-        if (precision == 64 && scene->info.max_depth + 1 > kPrimary64Stack)
+        if (precision == 64 && std::max(scene->info.max_depth, scene->bvh.flat_depth) + 1 > kPrimary64Stack)
             throw std::runtime_error("reference-topology BVH of depth " + std::to_string(scene->info.max_depth) +
                                      " exceeds the parity kernel's stack (" + std::to_string(kPrimary64Stack) + " entries)");
         DeviceGuard guard(scene->device);

@@ -379,6 +379,12 @@ struct Closest {
     int rank;       // rank of h.slot's surface (ties)
     uint32_t meta;  // meta word of h.slot (tree hits): type and material / index for the shade step
 };
+// t of the closest hit as exactly as it is known: the f64 root of a sphere or quad (loose, or a tree hit that is not a
+// triangle), the f32 t of a triangle; +inf before the first hit.
+__device__ __forceinline__ double closest_t64(const Closest& c) {
+    const bool has_root = c.h.slot <= -2 || (c.h.slot >= 0 && (c.meta & kMetaTypeMask) != 1u);
+    return has_root ? hit_get_t64(c.h) : (double)c.h.t;
+}
 __device__ __forceinline__ void closest_reset(Closest& c) {
     c.h.t = __builtin_inff();
     c.h.slot = -1;
@@ -403,20 +409,25 @@ template <bool STATS, bool EXT = false, class Recs>
 __device__ __forceinline__ void loose_hits(Recs recs, uint32_t n_loose, const Ray& ray, float tmin,
                                            Closest& best, TraceStats& st) {
     const D3 dd = d3(ray.d);
+    // The closest root so far in f64: these tests are the reference's own arithmetic, and an exact equal-t tie between
+    // two of them (coplanar quads) is decided on the f64 roots, as the reference decides it — on best.h.t, their f32
+    // rounding, a root that rounded DOWN shut the tie's other party out (t64 > (double)best.h.t) whatever its rank.
+    double best64 = closest_t64(best);
     for (uint32_t i = 0; i < n_loose; ++i) {
         const auto m = recs[kLooseRecQuads * i];
         double t;
         if (m.x == 0u) {
             if (STATS) st.spheres++;
             t = sphere_root_gated<EXT>(loose_data(recs, i), loose_data(recs, i) + 4, loose_data(recs, i) + 10, ray.time, ray.o,
-                                       dd, (double)tmin, (double)best.h.t);
+                                       dd, (double)tmin, best64);
         } else {
             if (STATS) st.quads++;
-            t = quad_root_gated(loose_data(recs, i), loose_data(recs, i) + 13, ray.o, dd, (double)tmin, (double)best.h.t);
+            t = quad_root_gated(loose_data(recs, i), loose_data(recs, i) + 13, ray.o, dd, (double)tmin, best64);
         }
-        const float tf = (float)t;
-        if (tf >= tmin && (tf < best.h.t || (tf == best.h.t && (int)m.z > best.rank))) {
-            best.h.t = tf, best.h.slot = -2 - (int)i, best.rank = (int)m.z;
+        // (a root lies in [tmin, best64] or is -1)
+        if (t >= 0.0 && (t < best64 || (int)m.z > best.rank)) {
+            best64 = t;
+            best.h.t = (float)t, best.h.slot = -2 - (int)i, best.rank = (int)m.z;
             hit_set_t64(best.h, t);
         }
     }
@@ -527,7 +538,7 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
     const uint32_t meta = __float_as_uint(p0.w);
     const uint32_t type = meta & kMetaTypeMask;
     float t = -1.f, bu = 0.f, bv = 0.f;
-    double t64 = -1.0;
+    double t64 = -1.0, best64 = 0.0;  // best64: the closest hit's t as closest_t64 gives it (sphere / quad tests only)
     // TREE: what the host found in the render tree — 1: nothing but triangles (every mesh scene), 2: nothing but
     // spheres (one-weekend), 3: nothing but quads (the cornell example), 0: a mix.  The tests that cannot occur are
     // not compiled in: each costs registers.
@@ -559,18 +570,22 @@ __device__ __forceinline__ bool prim_test(const DevScene& sc, const Ray& ray, co
     } else if (TREE == 2 || (TREE == 0 && type == 0u)) {  // only scenes with more than kMaxLoose spheres+quads keep them in the tree
         if (STATS) st.spheres++;
         const uint32_t si = meta >> kMetaIndexShift;
+        best64 = closest_t64(best);
         t64 = sphere_root_gated<EXT>(sc.spheres + 4 * si, sc.sphere_gate + 6 * si, sc.sphere_end + 3 * si, ray.time, ray.o,
-                                     d3(ray.d), (double)tmin, (double)best.h.t);
+                                     d3(ray.d), (double)tmin, best64);
         t = (float)t64;
     } else {
         if (STATS) st.quads++;
+        best64 = closest_t64(best);
         t64 = quad_root_gated(sc.quads + 16 * (meta >> kMetaIndexShift), sc.quad_gate + 6 * (meta >> kMetaIndexShift), ray.o,
-                              d3(ray.d), (double)tmin, (double)best.h.t);
+                              d3(ray.d), (double)tmin, best64);
         t = (float)t64;
     }
     if (t >= tmin && t <= best.h.t) {
         const int rank = __float_as_int(p1.w);
-        if (t < best.h.t || rank > best.rank) {
+        // a sphere's or quad's root is compared as the f64 number it is (see loose_hits); a triangle's t is f32
+        const bool nearer = (TREE != 1 && type != 1u) ? t64 < best64 : t < best.h.t;
+        if (nearer || rank > best.rank) {
             best.h.t = t, best.h.slot = slot, best.h.bu = bu, best.h.bv = bv, best.rank = rank, best.meta = meta;
             if (TREE != 1 && type != 1u) hit_set_t64(best.h, t64);
         }

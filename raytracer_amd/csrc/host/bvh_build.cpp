@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <future>
+#include <stdexcept>
 
 namespace rt {
 
@@ -222,8 +223,176 @@ Aabb true_bounds(const rt_scene_desc& d, const rt_surface_ref& s) {
     }
 }
 
+namespace {
+
+// ---- nested trees (rt_bvh_group; Surface::Bvh, surfaces.rs:374) ------------------------------------------------
+// Every group — and the scene's own list, "group -1" — gets a tree of its own over its members, a member being a
+// surface or a whole sub-group with one box, exactly as the reference's builds see them.  The trees are then laid
+// into ONE node array in in-order, so that Bvh::order is the reference's in-order leaf sequence with every nested
+// tree expanded in place.  A reference leaf [a, b, G, c] becomes the chain ((leaf[a, b], tree(G)), leaf[c]): an inner
+// node prefers its right child on a tie (bvh.rs:272-273) as a leaf prefers its later member (bvh.rs:308), so the
+// chain resolves every tie as the leaf does.  Node boxes are the world-space bounds of what lies below them.
+struct Nested {
+    const rt_scene_desc& d;
+    Bvh& out;
+    struct Tree {
+        Bvh t;                      // over the group's members; t.order: member codes (>= 0 surface id, < 0 ~group)
+        std::vector<int32_t> members;
+        Aabb build_box = Aabb::empty();  // union of the members' boxes in this group's build
+    };
+    std::vector<Tree> trees;  // [0] = the scene's own list, [g + 1] = group g
+
+    Nested(const rt_scene_desc& desc, Bvh& o) : d(desc), out(o), trees(desc.n_groups + 1) {}
+
+    Aabb member_box(int32_t code) const {
+        if (code < 0) {
+            const rt_bvh_group& g = d.groups[~code];
+            if (!(g.box[0] > g.box[3])) return Aabb{V3{g.box[0], g.box[1], g.box[2]}, V3{g.box[3], g.box[4], g.box[5]}};
+            return trees[(size_t)(~code) + 1].build_box;
+        }
+        if (d.surface_build_box) {
+            const double* b = d.surface_build_box + 6 * (size_t)code;
+            if (!(b[0] > b[3])) return Aabb{V3{b[0], b[1], b[2]}, V3{b[3], b[4], b[5]}};
+        }
+        return surface_bounds(d, d.surfaces[code]);
+    }
+
+    void collect_members() {
+        std::vector<uint8_t> listed(d.n_groups, 0);
+        for (size_t i = 0; i < d.n_surfaces; ++i) {
+            const int32_t g = d.surface_group[i];
+            // the groups on the way up that this surface is the first member of join their parents' lists first
+            std::vector<int32_t> chain;
+            for (int32_t k = g; k >= 0 && !listed[k]; k = d.groups[k].parent) chain.push_back(k);
+            for (size_t c = chain.size(); c-- > 0;) {
+                listed[chain[c]] = 1;
+                trees[(size_t)(d.groups[chain[c]].parent + 1)].members.push_back(~chain[c]);
+            }
+            trees[(size_t)(g + 1)].members.push_back((int32_t)i);
+        }
+    }
+
+    // the group's own tree (children first: a sub-group without a given box has its members' union)
+    void build_tree(int32_t g) {
+        Tree& tr = trees[(size_t)(g + 1)];
+        for (int32_t code : tr.members)
+            if (code < 0) build_tree(~code);
+        std::vector<Item> items(tr.members.size());
+        for (size_t i = 0; i < items.size(); ++i) {
+            items[i] = {member_box(tr.members[i]), tr.members[i]};
+            tr.build_box = tr.build_box.merge(items[i].box);
+        }
+        Builder b(items, &tr.t);
+        const bool one_leaf = g >= 0 ? d.groups[g].leaf != 0 : !d.use_bvh;
+        if (one_leaf) b.make_leaf(0, items.size(), 1);
+        else b.build(0, items.size(), 1);
+        tr.t.order.resize(items.size());
+        for (size_t i = 0; i < items.size(); ++i) tr.t.order[i] = items[i].id;
+    }
+
+    int32_t new_inner(int32_t l, int32_t r) {
+        BvhNode n;
+        n.left = l, n.right = r;
+        n.box = out.nodes[l].box.merge(out.nodes[r].box);
+        out.nodes.push_back(n);
+        return (int32_t)out.nodes.size() - 1;
+    }
+
+    // lays node `node` of group g's tree into `out`; depth: the reference's (root of the scene = 1), flat: the array's
+    int32_t emit(int32_t g, int32_t node, uint32_t depth, uint32_t flat) {
+        const Bvh& t = trees[(size_t)(g + 1)].t;
+        const BvhNode& n = t.nodes[node];
+        out.max_depth = std::max(out.max_depth, depth);
+        out.flat_depth = std::max(out.flat_depth, flat);
+        if (!n.is_leaf()) {
+            const int32_t self = (int32_t)out.nodes.size();
+            out.nodes.emplace_back();
+            const int32_t l = emit(g, n.left, depth + 1, flat + 1);
+            const int32_t r = emit(g, n.right, depth + 1, flat + 1);
+            BvhNode& me = out.nodes[self];
+            me.left = l, me.right = r;
+            me.box = out.nodes[l].box.merge(out.nodes[r].box);
+            return self;
+        }
+        out.n_leaves++;
+        out.max_leaf_size = std::max(out.max_leaf_size, (uint32_t)n.count);
+        // runs of surfaces and sub-trees, left to right
+        std::vector<int32_t> parts, runs;
+        int32_t k = n.first;
+        const int32_t end = n.first + n.count;
+        // (chain nodes sit above the parts: a part's flat depth is at most flat + number of parts - 1)
+        uint32_t n_parts = 0;
+        for (int32_t i = n.first; i < end;) {
+            if (t.order[i] < 0) ++n_parts, ++i;
+            else { ++n_parts; while (i < end && t.order[i] >= 0) ++i; }
+        }
+        const uint32_t part_flat = flat + (n_parts > 1 ? n_parts - 1 : 0);
+        do {
+            if (k < end && t.order[k] < 0) {
+                parts.push_back(emit(~t.order[k], 0, depth + 1, part_flat + 0));
+                ++k;
+                continue;
+            }
+            BvhNode leaf;
+            leaf.box = Aabb::empty();
+            leaf.first = (int32_t)out.order.size();
+            while (k < end && t.order[k] >= 0) {
+                leaf.box = leaf.box.merge(surface_bounds(d, d.surfaces[t.order[k]]));
+                out.order.push_back(t.order[k++]);
+            }
+            leaf.count = (int32_t)out.order.size() - leaf.first;
+            out.nodes.push_back(leaf);
+            out.flat_depth = std::max(out.flat_depth, part_flat);
+            parts.push_back((int32_t)out.nodes.size() - 1);
+            runs.push_back(parts.back());
+        } while (k < end);
+        int32_t top = parts[0];
+        for (size_t p = 1; p < parts.size(); ++p) top = new_inner(top, parts[p]);
+        if (parts.size() > 1)
+            for (int32_t r : runs) out.nodes[r].gate = top;
+        return top;
+    }
+
+    void run() {
+        for (size_t g = 0; g < d.n_groups; ++g)
+            if (d.groups[g].parent < -1 || d.groups[g].parent >= (int32_t)g)
+                throw std::runtime_error("rt_bvh_group: a group's parent must be listed before it");
+        for (size_t i = 0; i < d.n_surfaces; ++i)
+            if (d.surface_group[i] < -1 || d.surface_group[i] >= (int32_t)d.n_groups)
+                throw std::runtime_error("surface_group: group index out of range");
+        collect_members();
+        for (size_t g = 0; g < d.n_groups; ++g)
+            if (trees[g + 1].members.empty()) throw std::runtime_error("rt_bvh_group: a group without members");
+        build_tree(-1);
+        for (const Tree& tr : trees) out.nodes.reserve(out.nodes.size() + tr.t.nodes.size());
+        out.order.reserve(d.n_surfaces);
+        // the root must be node 0: an inner root reserves its slot first (emit does); a chain's top is made last
+        const int32_t root = emit(-1, 0, 1, 1);
+        if (root != 0) {  // the scene's own list is one leaf holding groups: move the chain's top to the front
+            std::swap(out.nodes[0], out.nodes[root]);
+            auto fix = [&](int32_t& r) { r = r == 0 ? root : (r == root ? 0 : r); };
+            for (BvhNode& n : out.nodes) {
+                if (!n.is_leaf()) fix(n.left), fix(n.right);
+                if (n.gate >= 0) fix(n.gate);
+            }
+        }
+        if (out.order.size() != d.n_surfaces) throw std::runtime_error("nested BVH build lost surfaces (groups not contiguous?)");
+        // the count of nodes as the reference's recursion sees them: every tree's own nodes
+        size_t n_ref_nodes = 0;
+        for (const Tree& tr : trees) n_ref_nodes += tr.t.nodes.size();
+        out.ref_nodes = n_ref_nodes;
+    }
+};
+
+}  // namespace
+
 void build_bvh(const rt_scene_desc& d, Bvh& out) {
     out = Bvh{};
+    if (d.n_groups > 0 && d.surface_group) {
+        Nested nested(d, out);
+        nested.run();
+        return;
+    }
     std::vector<Item> items(d.n_surfaces);
     for (size_t i = 0; i < d.n_surfaces; ++i) items[i] = {surface_bounds(d, d.surfaces[i]), (int32_t)i};
     Builder b(items, &out);

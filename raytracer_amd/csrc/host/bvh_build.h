@@ -16,6 +16,10 @@ struct BvhNode {
     Aabb box;
     int32_t left = -1, right = -1;  // inner: node indices; leaf: -1
     int32_t first = 0, count = 0;   // leaf: range in Bvh::order
+    // A leaf of the reference that holds nested trees among its surfaces (rt_bvh_group) is laid out as a chain of
+    // inner nodes over its runs of surfaces and its sub-trees (build_bvh); `gate` then names the chain's top node,
+    // whose box is the reference leaf's (what a surface's gate is taken from, device_rt.h leaf_gate_hit); -1: its own.
+    int32_t gate = -1;
     bool is_leaf() const { return left < 0; }
 };
 
@@ -25,6 +29,11 @@ struct Bvh {
     uint32_t max_depth = 0;       // root = 1
     uint32_t max_leaf_size = 0;
     uint32_t n_leaves = 0;
+    // With nested groups the figures above count as the reference's recursion does (a nested tree's nodes and
+    // leaves are counted, its root one level below the leaf that holds it, a group one member of that leaf); the
+    // node array itself is then deeper by the chains: `flat_depth` (0: same as max_depth).
+    uint32_t flat_depth = 0;
+    size_t ref_nodes = 0;  // nodes as the reference counts them (0: nodes.size())
 };
 
 // Bounding box of one surface: surfaces.rs:57-69 (sphere), 281-291 (triangle), 356-359 (quad).

@@ -6,6 +6,7 @@
 // the draws come from a splitmix64 stream seeded by the caller, in the reference's order of draws.
 // Its instancing wrappers (Rotated about the bounding box's centroid, then Translated, surfaces.rs:461-534)
 // are baked into the quads, as the YAML loader does for `box` (load.rs:90-156).
+#include <algorithm>
 #include <cmath>
 #include <stdexcept>
 #include <utility>
@@ -39,6 +40,42 @@ int add_material(HostScene& hs, int kind, V3 albedo, double param) {
     return (int)hs.materials.size() - 1;
 }
 
+// ---- nesting (rt_bvh_group): which Bvh of the reference a surface is added to.  `g_current` is the group the
+// next surfaces join (-1: the SceneBuilder's own list); every add_* below notes it.
+thread_local int g_current = -1;
+const double kNoBox[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+void note_surface(HostScene& hs, const double* build_box = nullptr) {
+    hs.surface_group.push_back(g_current);
+    const double* b = build_box ? build_box : kNoBox;
+    hs.surface_build_box.insert(hs.surface_build_box.end(), b, b + 6);
+}
+// Opens a group inside the current one; returns its index.  `box`: what the parent's build sees (null: the union
+// of the members' boxes, Bvh::bounding_box of an unwrapped tree).
+int open_group(HostScene& hs, bool leaf, const double* box = nullptr) {
+    rt_bvh_group g{};
+    g.parent = g_current, g.leaf = leaf ? 1 : 0;
+    for (int a = 0; a < 6; ++a) g.box[a] = box ? box[a] : kNoBox[a];
+    hs.groups.push_back(g);
+    return g_current = (int)hs.groups.size() - 1;
+}
+void close_group(HostScene& hs) { g_current = hs.groups[(size_t)g_current].parent; }
+
+// Aabb::rotate about +y by `degrees` (trace.rs:191-211: the eight corners turned about the box's midpoint), then
+// Aabb::translate (trace.rs:185-189): the box of Translated::new(Rotated::new(x, jhat, angle), offset).
+void wrapped_box(V3 lo, V3 hi, double degrees, V3 offset, double* out6) {
+    const V3 delta = hi - lo, mid = lo + 0.5 * delta;
+    const Quat rot = Quat::rotation(V3{0, 1, 0}, degrees * 0.017453292519943295);
+    V3 mn{INFINITY, INFINITY, INFINITY}, mx{-INFINITY, -INFINITY, -INFINITY};
+    for (int ii = 0; ii < 8; ++ii) {
+        const V3 corner = lo + V3{(double)(ii & 1) * delta.x, (double)((ii >> 1) & 1) * delta.y, (double)((ii >> 2) & 1) * delta.z};
+        const V3 r = rotate_point(rot, mid, corner);
+        mn = vmin(mn, r), mx = vmax(mx, r);
+    }
+    mn = mn + offset, mx = mx + offset;
+    out6[0] = mn.x, out6[1] = mn.y, out6[2] = mn.z, out6[3] = mx.x, out6[4] = mx.y, out6[5] = mx.z;
+}
+
 void add_sphere(HostScene& hs, V3 c, double r, int material) {
     rt_sphere s{};
     s.center[0] = s.center1[0] = c.x, s.center[1] = s.center1[1] = c.y, s.center[2] = s.center1[2] = c.z;
@@ -46,11 +83,13 @@ void add_sphere(HostScene& hs, V3 c, double r, int material) {
     s.material = material;
     hs.surfaces.push_back(rt_surface_ref{RT_SURF_SPHERE, (int32_t)hs.spheres.size()});
     hs.spheres.push_back(s);
+    note_surface(hs);
 }
 
 void add_quad(HostScene& hs, V3 q, V3 u, V3 v, int material) {
     hs.surfaces.push_back(rt_surface_ref{RT_SURF_QUAD, (int32_t)hs.quads.size()});
     hs.quads.push_back(make_quad(q, u, v, material));
+    note_surface(hs);
 }
 
 // make_box (surfaces.rs:542-590), Rotated::new about the box's centroid (surfaces.rs:507-534) by
@@ -66,6 +105,14 @@ void add_box(HostScene& hs, V3 a, V3 b, int material, double degrees, V3 offset,
     const V3 blo = lo - pad, bhi = hi + pad;
     const V3 centre = blo + 0.5 * (bhi - blo);
     const Quat rot = Quat::rotation(V3{0, 1, 0}, degrees * 0.017453292519943295);
+    // As surfaces the six quads are one Bvh::new_leaf (make_box) inside whatever the box is added to; where the
+    // example wraps it (cornell: Rotated, then Translated) the parent's build sees the wrapped box.
+    if (as_surfaces) {
+        double box[6];
+        const bool wrapped = degrees != 0.0 || offset.x != 0.0 || offset.y != 0.0 || offset.z != 0.0;
+        if (wrapped) wrapped_box(blo, bhi, degrees, offset, box);
+        open_group(hs, true, wrapped ? box : nullptr);
+    }
     auto put = [&](V3 q, V3 u, V3 v) {
         const V3 p0 = rotate_point(rot, centre, q) + offset;
         const V3 p1 = rotate_point(rot, centre, q + u) + offset;
@@ -79,6 +126,7 @@ void add_box(HostScene& hs, V3 a, V3 b, int material, double degrees, V3 offset,
     put(V3{lo.x, lo.y, lo.z}, dz, dy);              // left
     put(V3{lo.x, hi.y, hi.z}, dx, -1.0 * dz);       // top
     put(V3{lo.x, lo.y, lo.z}, dx, dz);              // bottom
+    if (as_surfaces) close_group(hs);
 }
 
 // ConstantMedium::new(boundary, d, albedo), surfaces.rs:601-608, over boundary primitives added just before
@@ -89,6 +137,7 @@ void add_medium(HostScene& hs, int boundary, int first, int count, double densit
     m.density = density;
     hs.surfaces.push_back(rt_surface_ref{RT_SURF_MEDIUM, (int32_t)hs.media.size()});
     hs.media.push_back(m);
+    note_surface(hs);
 }
 
 void one_weekend(double aspect_ratio, uint64_t seed, HostScene& hs) {
@@ -96,6 +145,7 @@ void one_weekend(double aspect_ratio, uint64_t seed, HostScene& hs) {
     hs.desc.background[0] = 0.7, hs.desc.background[1] = 0.8, hs.desc.background[2] = 1.0;
     Draws rng{seed};
     add_sphere(hs, V3{0, -1000, 0}, 1000.0, add_material(hs, RT_MAT_LAMBERTIAN, V3{0.5, 0.5, 0.5}, 0));
+    open_group(hs, false);  // `surfaces = Bvh::builder()` (example.rs:96), added to the scene at :139
     for (int a = -11; a < 11; ++a)
         for (int b = -11; b < 11; ++b) {
             const double choose = rng.next();
@@ -118,6 +168,7 @@ void one_weekend(double aspect_ratio, uint64_t seed, HostScene& hs) {
     add_sphere(hs, V3{-4, 1, 0}, 1.0, add_material(hs, RT_MAT_LAMBERTIAN, V3{0.05, 0.2, 0.6}, 0));
     add_sphere(hs, V3{0, 1, 0}, 1.0, add_material(hs, RT_MAT_DIELECTRIC, V3{1, 1, 1}, 1.5));
     add_sphere(hs, V3{4, 1, 0}, 1.0, add_material(hs, RT_MAT_METAL, V3{0.7, 0.6, 0.5}, 0.0));
+    close_group(hs);
 }
 
 int add_textured(HostScene& hs, int texture, V3 even, V3 odd, double scale, int index) {
@@ -257,11 +308,13 @@ void final_scene(double aspect_ratio, uint64_t seed, HostScene& hs) {
     hs.desc.background[0] = hs.desc.background[1] = hs.desc.background[2] = 0.0;
     Draws rng{seed};
     const int ground = add_material(hs, RT_MAT_LAMBERTIAN, V3{0.48, 0.83, 0.53}, 0);
+    open_group(hs, false);  // Bvh::new(boxes1), example.rs:498: a tree whose 400 members are make_box leaves
     for (int i = 0; i < 20; ++i)
         for (int j = 0; j < 20; ++j) {
             const double w = 100.0, x0 = -1000.0 + i * w, z0 = -1000.0 + j * w, y1 = rng.range(1.0, 101.0);
             add_box(hs, V3{x0, 0.0, z0}, V3{x0 + w, y1, z0 + w}, ground, 0.0, V3{0, 0, 0});
         }
+    close_group(hs);
     add_quad(hs, V3{123, 554, 147}, V3{300, 0, 0}, V3{0, 0, 265}, add_material(hs, RT_MAT_DIFFUSE_LIGHT, V3{7, 7, 7}, 0));
     add_sphere(hs, V3{400, 400, 200}, 50.0, add_material(hs, RT_MAT_LAMBERTIAN, V3{0.7, 0.3, 0.1}, 0));
     hs.spheres.back().moving = 1;  // Sphere::moving(center1, center1 + (30, 0, 0), ...)
@@ -295,12 +348,23 @@ void final_scene(double aspect_ratio, uint64_t seed, HostScene& hs) {
     }
     const V3 centre = lo + 0.5 * (hi - lo);  // Aabb::centroid of the cluster's box (Rotated::new, surfaces.rs:507-517)
     const Quat rot = Quat::rotation(V3{0, 1, 0}, 15.0 * 0.017453292519943295);
-    for (const V3& p : pts) add_sphere(hs, rotate_point(rot, centre, p) + V3{-100, 270, 395}, 10.0, white);
+    // Translated::new(Rotated::new(Bvh::new(boxes2), ..)): the cluster's tree is built over the spheres where they
+    // were drawn (their boxes in the cluster's own space: surface_build_box); the scene's build sees the turned box
+    double cluster_box[6];
+    wrapped_box(lo, hi, 15.0, V3{-100, 270, 395}, cluster_box);
+    open_group(hs, false, cluster_box);
+    for (const V3& p : pts) {
+        add_sphere(hs, rotate_point(rot, centre, p) + V3{-100, 270, 395}, 10.0, white);
+        const double own[6] = {p.x - 10, p.y - 10, p.z - 10, p.x + 10, p.y + 10, p.z + 10};
+        std::copy(own, own + 6, hs.surface_build_box.end() - 6);
+    }
+    close_group(hs);
 }
 
 }  // namespace
 
 void example_scene(const std::string& name, double aspect_ratio, uint64_t seed, bool use_bvh, HostScene& out) {
+    g_current = -1;
     if (name == "one-weekend") one_weekend(aspect_ratio, seed, out);
     else if (name == "cornell") cornell(aspect_ratio, out);
     else if (name == "random-spheres") random_spheres(aspect_ratio, seed, out);
@@ -311,6 +375,7 @@ void example_scene(const std::string& name, double aspect_ratio, uint64_t seed, 
     else if (name == "final-scene") final_scene(aspect_ratio, seed, out);
     else
         throw std::runtime_error("invalid value '" + name + "' for '--example <EXAMPLE>'");  // Example::from_str
+    g_current = -1;
     out.desc.use_bvh = use_bvh ? 1 : 0;
     out.sync_desc();
 }

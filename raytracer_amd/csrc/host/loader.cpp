@@ -266,6 +266,11 @@ void HostScene::sync_desc() {
     desc.perlin = perlin.data(), desc.n_perlin = perlin.size();
     for (size_t i = 0; i < images.size() && i < image_data.size(); ++i) images[i].rgb = image_data[i].data();
     desc.images = images.data(), desc.n_images = images.size();
+    // nesting: only when a group exists, and then one group entry (and one build box, if any) per surface
+    const bool nested = !groups.empty() && surface_group.size() == surfaces.size();
+    desc.groups = nested ? groups.data() : nullptr, desc.n_groups = nested ? groups.size() : 0;
+    desc.surface_group = nested ? surface_group.data() : nullptr;
+    desc.surface_build_box = nested && surface_build_box.size() == 6 * surfaces.size() ? surface_build_box.data() : nullptr;
 }
 
 rt_quad make_quad(V3 q, V3 u, V3 v, int material) {

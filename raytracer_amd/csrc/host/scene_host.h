@@ -21,6 +21,10 @@ struct HostScene {
     std::vector<rt_perlin> perlin;
     std::vector<rt_image> images;
     std::vector<std::vector<uint8_t>> image_data;  // pixels behind `images`
+    // nesting of the reference-topology tree (rt_bvh_group): empty for scene files
+    std::vector<rt_bvh_group> groups;
+    std::vector<int32_t> surface_group;      // per surface once any group exists (kept in step by the example generators)
+    std::vector<double> surface_build_box;   // 6 per surface, or empty
     void sync_desc();  // refresh desc pointers/counts after the vectors changed
 };
 

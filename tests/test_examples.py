@@ -171,12 +171,132 @@ def test_deterministic_examples_match_the_independent_restatement(ra, name):
             g = quads[m["first"] + j]
             assert np.array_equal(g["q"], q) and np.array_equal(g["u"], u) and np.array_equal(g["v"], v), (name, k, j)
         assert surf[len(shown) + k]["type"] == 3 and surf[len(shown) + k]["index"] == k
+    # nesting (Surface::Bvh): cornell's two boxes are one-leaf trees inside the scene's list, with the wrapped boxes'
+    # bounds; the other three have none
+    groups = want.get("groups", [])
+    assert len(d.groups) == len(groups)
+    if groups:
+        assert d.surface_group.tolist() == want["surface_group"]
+        for g, (parent, leaf, box) in zip(d.groups, groups):
+            assert (int(g["parent"]), int(g["leaf"])) == (parent, leaf) and np.array_equal(g["box"], box), (g, box)
+        assert d.surface_build_box is None or (d.surface_build_box[:, 0] > d.surface_build_box[:, 3]).all()
+    else:
+        assert d.surface_group is None
     if name == "earth":  # the missing earth.png: an image texture without pixels shades the fallback colour
         assert len(d.images) == 1 and d.images[0].size == 0
     # the camera: Camera::builder defaults (no aperture, focus distance |from - towards|), camera.rs:43-74
     fov, frm, to, aperture, focus = want["camera"]
     assert aperture == 0.0 and focus is None and d.camera.lens_radius == 0.0
     assert CAMERAS[name](1.25)[:8] == [fov, 1.25, *frm, *to]
+
+
+ALL_EXAMPLES = ["one-weekend", "random-spheres", "two-spheres", "two-perlin", "earth", "cornell", "cornell-smoke", "final-scene"]
+
+
+@pytest.mark.parametrize("name", ALL_EXAMPLES)
+def test_examples_nest_their_trees_like_the_reference(ra, ref, name):
+    """Surface::Bvh (surfaces.rs:374): a tree as ONE member of another tree's leaf.  one-weekend adds the ground to the
+    scene and everything else to a Bvh of its own (example.rs:96-139); make_box is a one-leaf Bvh (surfaces.rs:591), so
+    cornell's scene list holds 6 quads + 2 trees; final-scene holds a tree of 400 such boxes and, wrapped in Rotated and
+    Translated, a tree of 1000 spheres built where the spheres were drawn (example.rs:474-498, 553-570).  The product's
+    build (host only here) and the oracle's — two implementations, the oracle's in the reference's own recursive form —
+    must give the same in-order leaf sequence and the same tree figures."""
+    aspect = 1.0
+    d = ra.example_scene(name, aspect, seed=11)
+    s = ra.Scene(d, ra.RT_DEVICE_NONE)
+    order, st = ref.RefScene.from_desc(d, CAMERAS[name](aspect)).leaf_order()
+    info, mine = s.info(), s.leaf_order()
+    assert np.array_equal(mine, order) and sorted(order.tolist()) == list(range(d.n_surfaces))
+    assert (info.n_nodes, info.n_leaves, info.max_depth, info.max_leaf_size) == (st["nodes"], st["leaves"], st["depth"], st["max_leaf"])
+    g, sg = d.groups, d.surface_group
+    if name == "one-weekend":
+        assert len(g) == 1 and (g["parent"][0], g["leaf"][0]) == (-1, 0) and sg[0] == -1 and np.all(sg[1:] == 0)
+        assert order[0] == 0      # the scene's list is the leaf [ground, tree]: the ground loses every tie to a sphere on it
+    elif name == "cornell":
+        assert len(g) == 2 and g["leaf"].tolist() == [1, 1] and sg.tolist() == [-1] * 6 + [0] * 6 + [1] * 6
+        assert order.tolist() == list(range(18))  # 8 members: one leaf, in listing order, the boxes' leaves in place
+        assert (info.n_nodes, info.n_leaves, info.max_depth, info.max_leaf_size) == (3, 3, 2, 8)
+    elif name == "final-scene":
+        assert len(g) == 402 and g["parent"][0] == -1 and np.all(g["parent"][1:401] == 0) and np.all(g["leaf"][1:401] == 1)
+        assert (g["parent"][401], g["leaf"][401]) == (-1, 0) and g["box"][401][0] < g["box"][401][3]  # the turned cluster's box
+        pos = np.empty(d.n_surfaces, dtype=np.int64)
+        pos[order] = np.arange(d.n_surfaces)
+        boxes = pos[:2400].reshape(400, 6)                      # a box's six quads: adjacent and in make_box's order
+        assert np.all(np.diff(boxes, axis=1) == 1)
+        tree_of_boxes = np.sort(pos[:2400])
+        assert tree_of_boxes[-1] - tree_of_boxes[0] == 2399     # the tree of boxes is one run of the sequence
+        cluster = np.sort(pos[sg == 401])
+        assert len(cluster) == 1000 and cluster[-1] - cluster[0] == 999
+        bb = d.surface_build_box
+        assert np.allclose(bb[sg == 401][:, 3:] - bb[sg == 401][:, :3], 20.0) and np.all(bb[sg != 401][:, 0] > bb[sg != 401][:, 3])
+    else:
+        assert len(g) == 0 and sg is None  # random-spheres adds every sphere to the scene itself (example.rs:153-203)
+    s.close()
+
+
+def _tie_scene(ra, nested):
+    """20 small quads in the plane y = 0 and, LISTED LAST, one large quad in the same plane under all of them: every ray
+    that meets a small quad meets the large one at the very same t.  `nested`: the small quads are a Bvh of their own."""
+    from raytracer_amd.api import GROUP_DTYPE, MATERIAL_DTYPE, QUAD_DTYPE, SPHERE_DTYPE, SURFACE_DTYPE, TRIANGLE_DTYPE
+
+    def quad(q, u, v, material):
+        r = np.zeros((), dtype=QUAD_DTYPE)
+        n = np.cross(u, v)
+        normal = n / np.sqrt(n @ n)
+        r["q"], r["u"], r["v"], r["normal"], r["d"], r["w"], r["material"] = q, u, v, normal, normal @ np.asarray(q, float), n / (n @ n), material
+        return r
+
+    quads = [quad((-2.0 + 0.8 * (k % 5), 0.0, -1.6 + 0.8 * (k // 5)), (0.5, 0.0, 0.0), (0.0, 0.0, 0.5), 0) for k in range(20)]
+    quads.append(quad((-50.0, 0.0, -50.0), (100.0, 0.0, 0.0), (0.0, 0.0, 100.0), 1))
+    mats = np.zeros(2, dtype=MATERIAL_DTYPE)
+    mats["albedo"] = [(0.8, 0.2, 0.2), (0.2, 0.2, 0.8)]
+    surfaces = np.array([(2, k) for k in range(21)], dtype=SURFACE_DTYPE)
+    cam = ra.example_scene("two-spheres", 1.0).camera  # from (13, 2, 3) towards the origin, fov 20
+    groups = np.array([(-1, 0, (1, 0, 0, 0, 0, 0))], dtype=GROUP_DTYPE) if nested else None
+    return ra.SceneDesc.from_arrays(mats, np.zeros(0, SPHERE_DTYPE), np.zeros(0, TRIANGLE_DTYPE), np.array(quads), surfaces,
+                                    (0.7, 0.8, 1.0), cam, groups=groups, surface_group=[0] * 20 + [-1] if nested else None)
+
+
+def test_nesting_decides_exact_ties(ra, ref):
+    """What the nesting changes: the in-order leaf sequence, hence the winner of an exact equal-t tie (the later one,
+    bvh.rs:272-273, 308).  Flat, the reference's stable sort by box minimum puts the large quad (its minimum is the
+    smallest) FIRST: a small quad wins the tie.  With the small quads in a Bvh of their own the scene's list is the
+    leaf [tree, large quad]: the large quad comes LAST and wins."""
+    w = h = 64
+    for nested, winner_is_large in ((False, False), (True, True)):
+        d = _tie_scene(ra, nested)
+        o = ref.RefScene.from_desc(d, CAMERAS["two-spheres"](1.0))
+        ids, t = o.primary_hits(w, h)
+        s = ra.Scene(d, ra.RT_DEVICE_NONE)
+        order = s.leaf_order()
+        assert np.array_equal(order, o.leaf_order()[0])
+        assert (order[-1] == 20) == winner_is_large and (order[0] == 20) == (not winner_is_large)
+        # pixels whose centre ray meets a small quad (the flat case names them; the nested case must name the large quad there)
+        if not nested:
+            on_small = ids < 20
+            assert on_small.sum() > 50 and np.all(ids[~on_small & (ids >= 0)] == 20)
+            small_pixels, small_t = on_small & (ids >= 0), t.copy()
+        else:
+            assert np.all(ids[small_pixels] == 20) and np.array_equal(t[small_pixels], small_t[small_pixels])
+        s.close()
+
+
+@pytest.mark.gpu
+def test_nesting_decides_exact_ties_on_the_gpu(ra, ref):
+    """The same two scenes through the C ABI: the f64 parity kernel (which resolves ties by the position in the in-order
+    sequence) and the f32 render path (which resolves them by rank) both name the oracle's winner."""
+    w = h = 64
+    for nested in (False, True):
+        d = _tie_scene(ra, nested)
+        want_ids, want_t = ref.RefScene.from_desc(d, CAMERAS["two-spheres"](1.0)).primary_hits(w, h)
+        s = ra.Scene(d, 0)
+        ids, t = s.primary_hits(w, h, precision=64)
+        assert np.array_equal(ids, want_ids) and np.array_equal(t, want_t)
+        ids32, _ = s.primary_hits(w, h, precision=32)
+        # f32 may round the two coplanar quads' t apart, but never towards the other winner where f64 ties exactly:
+        # both planes are y = 0 with the same normal, so the f32 t's are equal too
+        assert np.array_equal(ids32, want_ids)
+        s.close()
 
 
 @pytest.mark.gpu
