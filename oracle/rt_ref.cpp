@@ -9,8 +9,11 @@
 // Aabb::{centroid,surface_area}, Sphere::bounding_box and the quaternion algebra (trace.rs:247-263,
 // surfaces.rs:665-681, geom.rs:493-562); tests/test_oracle_kat.py checks those against this file and
 // oracle/loader_ref.py.  Intersection, traversal, scatter and the integrator are pinned by NO reference
-// test or golden image, so for them the status is "parity unpinned" (see DESIGN.md): they are checked by
-// hand-derived analytic cases only.
+// test or golden image, so for them the status is "parity unpinned" (see DESIGN.md): what holds them is
+// hand-derived — single-ray analytic cases (tests/test_oracle_kat.py) and closed-form image truths derived on paper
+// from the reference's sources (tests/analytic.py: furnaces, a sphere light's cosine law, the fuzzy-metal quirk, the
+// thin lens, Schlick's split and Snell's direction through a glass pane, a medium's free path, a moving sphere's
+// shutter share, the checker and uv textures), which this file and the GPU path must both meet.
 //
 // One deliberate difference: the random stream.  The reference draws from rand 0.8.2 SmallRng seeded per
 // rayon split (main.rs:154), which is not reproducible even with --seed.  The oracle keeps the
