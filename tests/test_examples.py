@@ -232,6 +232,16 @@ def test_examples_nest_their_trees_like_the_reference(ra, ref, name):
     else:
         assert len(g) == 0 and sg is None  # random-spheres adds every sphere to the scene itself (example.rs:153-203)
     s.close()
+    # --no-bvh makes ONE leaf of the scene's own list (scene/mod.rs:60-65); the trees inside it stay trees
+    flat_d = ra.example_scene(name, aspect, seed=11, use_bvh=False)
+    flat_s = ra.Scene(flat_d, ra.RT_DEVICE_NONE)
+    flat_order, flat_st = ref.RefScene.from_desc(flat_d, CAMERAS[name](aspect), use_bvh=False).leaf_order()
+    fi = flat_s.info()
+    assert np.array_equal(flat_s.leaf_order(), flat_order)
+    assert (fi.n_nodes, fi.n_leaves, fi.max_depth, fi.max_leaf_size) == (flat_st["nodes"], flat_st["leaves"], flat_st["depth"], flat_st["max_leaf"])
+    if name == "final-scene":
+        assert fi.max_leaf_size == 11 and fi.n_nodes > 400  # the scene's 11 members in one leaf, the nested trees intact
+    flat_s.close()
 
 
 def _tie_scene(ra, nested):
