@@ -102,34 +102,14 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 // flat_load, which counts on the LDS/scalar counter as well as on the vector-memory one — so the wait for a scalar load
 // (the next array's address) also waited for every vector load in flight, and the material fetch and the normal fetch
 // of a hit, meant to overlap, ran one after the other.  Typed as address space 1 they are global_load again.
-#ifndef RT_EAGER_V0
-#define RT_EAGER_V0 1
-#endif
-#ifndef RT_GLOBAL_LOADS
-#define RT_GLOBAL_LOADS 1
-#endif
 typedef float F32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_global(const float4* p) {
-#if RT_GLOBAL_LOADS
     const F32x4 v = *(const F32x4 __attribute__((address_space(1)))*)(uintptr_t)p;
     return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
 }
-__device__ __forceinline__ int load_global(const int* p) {
-#if RT_GLOBAL_LOADS
-    return *(const int __attribute__((address_space(1)))*)(uintptr_t)p;
-#else
-    return *p;
-#endif
-}
+__device__ __forceinline__ int load_global(const int* p) { return *(const int __attribute__((address_space(1)))*)(uintptr_t)p; }
 __device__ __forceinline__ double load_global(const double* p) {
-#if RT_GLOBAL_LOADS
     return *(const double __attribute__((address_space(1)))*)(uintptr_t)p;
-#else
-    return *p;
-#endif
 }
 
 // util.rs:15-24 / 26-35.  Two samplers with the same distributions:
@@ -610,12 +590,10 @@ __device__ __forceinline__ void leaf_step(const DevScene& sc, const Ray& ray, co
     }
     const float4 a0 = sc.prims[3 * slot + 0], a1 = sc.prims[3 * slot + 1], a2 = sc.prims[3 * slot + 2];
     const float4 b0 = sc.prims[3 * slot + 3], b1 = sc.prims[3 * slot + 4], b2 = sc.prims[3 * slot + 5];
-#if RT_EAGER_V0
     // the first triangle's v0 is needed only once its determinant has passed, and the compiler moves its fetch down
     // there: a second memory round trip inside the leaf trip for nearly every lane.  A use right here keeps the fetch
     // among the others.
     asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a0.z));
-#endif
     if (prim_test<STATS, EXT, TREE>(sc, ray, r, tmin, slot, a0, a1, a2, best, st)) return;
     if (prim_test<STATS, EXT, TREE>(sc, ray, r, tmin, slot + 1, b0, b1, b2, best, st)) return;
     slot += 2;
@@ -882,9 +860,6 @@ __device__ __forceinline__ F3 texture_color(const DevScene& sc, int mat, F3 albe
 }
 
 // `meta` is the hit slot's meta word (Closest::meta; tree hits only), `recs` the loose records as in loose_hits.
-#ifndef RT_HOIST_NORMALS
-#define RT_HOIST_NORMALS 0
-#endif
 // TRI: the render tree holds nothing but triangles (a tree hit is a triangle; spheres and quads are loose).
 template <bool DIRECT, bool EXT = false, bool NOISE = true, bool TRI = false>
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* recs, Ray& ray, const HitRec& hit,
@@ -911,15 +886,9 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
     // type and material first: the material fetch then overlaps the normal fetch
     uint32_t type, index;
     int mat;
-    // With a triangles-only tree the vertex normals are fetched here, in the same breath as the material: where they
-    // stood under `type == 1u` below, the compiler made their fetch wait for the material's (a second memory round
-    // trip in every shade trip).  A lane whose hit is a loose sphere or quad fetches slot 0's and ignores them.
-    constexpr bool kHoist = TRI && RT_HOIST_NORMALS;
-    float4 s0 = {}, s1 = {}, s2 = {};
-    if (kHoist) {
-        const int ns = hit.slot >= 0 ? hit.slot : 0;
-        s0 = load_global(sc.tri_shade + 3 * ns + 0), s1 = load_global(sc.tri_shade + 3 * ns + 1), s2 = load_global(sc.tri_shade + 3 * ns + 2);
-    }
+    // (The vertex normals are fetched under `type == 1u` below, after the material's fetch has come back: fetched here,
+    // beside it — one memory round trip instead of two — they cost ten more live registers, 16 spilled dwords instead
+    // of 6 in the six-wave build, and 12 % of the frame rate: profiles/r3_experiments.md.)
     if (hit.slot >= 0) {
         type = TRI ? 1u : (meta & kMetaTypeMask), index = meta >> kMetaIndexShift;
         mat = type == 1u ? (int)index : (type == 0u ? load_global(sc.sphere_mat + index) : load_global(sc.quad_mat + index));
@@ -933,11 +902,9 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, const uint4* re
     F3 n;
     D3 p;
     if (type == 1u) {
-        if (!kHoist) {
-            s0 = load_global(sc.tri_shade + 3 * hit.slot + 0);
-            s1 = load_global(sc.tri_shade + 3 * hit.slot + 1);
-            s2 = load_global(sc.tri_shade + 3 * hit.slot + 2);
-        }
+        const float4 s0 = load_global(sc.tri_shade + 3 * hit.slot + 0);
+        const float4 s1 = load_global(sc.tri_shade + 3 * hit.slot + 1);
+        const float4 s2 = load_global(sc.tri_shade + 3 * hit.slot + 2);
         // un-normalised barycentric blend (Q3), surfaces.rs:277
         n = hit.bu * f3(s1) + hit.bv * f3(s2) + (1.0f - hit.bu - hit.bv) * f3(s0);
         p = ray.o + (double)hit.t * dd;
