@@ -60,12 +60,12 @@ typedef struct rt_sphere {
 } rt_sphere;
 
 /* ConstantMedium, surfaces.rs:594-653: a boundary filled with an isotropic scatterer of constant density.
- * The boundary is one sphere (spheres[first]) or the quads of one make_box (quads[first .. first+count),
- * surfaces.rs:542-590); boundary primitives are NOT listed in `surfaces` (a scene that also shows the boundary
+ * The boundary is one sphere (spheres[first]) or a closed surface of quads (quads[first .. first+count): the six of
+ * one make_box, surfaces.rs:542-590, or any number); boundary primitives are NOT listed in `surfaces` (a scene that also shows the boundary
  * as a surface lists a copy).  The medium itself is listed in `surfaces` as {RT_SURF_MEDIUM, index}. */
 typedef struct rt_medium {
     int32_t boundary;  /* RT_SURF_SPHERE | RT_SURF_QUAD */
-    int32_t first, count; /* one sphere, or the quads of a box (at most six) */
+    int32_t first, count; /* one sphere (count 1), or `count` quads that enclose a volume (a make_box's six, or more) */
     int32_t material;  /* an RT_MAT_ISOTROPIC material */
     double density;
 } rt_medium;

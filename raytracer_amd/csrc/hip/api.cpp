@@ -204,7 +204,6 @@ void validate(const rt_scene_desc& d) {
         const size_t n = m.boundary == RT_SURF_SPHERE ? d.n_spheres : m.boundary == RT_SURF_QUAD ? d.n_quads : 0;
         if (m.first < 0 || m.count < 1 || (size_t)m.first + (size_t)m.count > n || (m.boundary == RT_SURF_SPHERE && m.count != 1))
             throw std::runtime_error("medium boundary out of range");
-        if (m.boundary == RT_SURF_QUAD && m.count > 6) throw std::runtime_error("a medium's boundary is one sphere or the (up to six) quads of a box");
     }
     if (d.n_media > kMaxMedia) throw std::runtime_error("too many media (at most " + std::to_string(kMaxMedia) + ")");
     if (d.n_groups > 0 && (!d.groups || !d.surface_group)) throw std::runtime_error("groups given without surface_group");

@@ -683,6 +683,21 @@ __device__ __attribute__((noinline)) void media_spans_impl(const DevMedium* medi
                 const double t0 = (-half_b - root) * ia, t1 = (-half_b + root) * ia;
                 if (t1 >= t0 + 0.0001) sp.t_in[k] = t0, sp.t_out[k] = t1;  // the second Sphere::hit, on (t0 + 0.0001, inf)
             }
+        } else if (m.count > 6) {
+            // a boundary of any number of quads (the reference takes any Hittable, surfaces.rs:601-608): the closest
+            // root, then the closest root beyond it — the two Quad::hit passes as they stand, nothing kept between them
+            double first = inf, second = inf;
+            for (int32_t q = 0; q < m.count; ++q) {
+                const double t = quad_root(quads + 16 * (m.first + q), o, dd, -inf, inf);
+                if (t >= 0.0 && t <= first) first = t;
+            }
+            if (first < inf) {
+                for (int32_t q = 0; q < m.count; ++q) {
+                    const double t = quad_root(quads + 16 * (m.first + q), o, dd, -inf, inf);
+                    if (t >= first + 0.0001 && t <= second) second = t;
+                }
+                if (second < inf) sp.t_in[k] = first, sp.t_out[k] = second;
+            }
         } else {
             // the six sides once: the second Quad::hit pass, on (first + 0.0001, inf), sees the same roots
             double tq[6], first = inf, second = inf;

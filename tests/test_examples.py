@@ -120,6 +120,66 @@ def test_a_fifth_medium_is_refused_with_a_message(ra):
         ra.Scene(make(5, len(d.surfaces) + 3), ra.RT_DEVICE_NONE)
 
 
+def _smoke_with_split_sides(ra):
+    """cornell-smoke with the tall box's boundary given as TEN quads instead of six: every side face cut into a lower and
+    an upper half (same planes, same solid).  Returns (that description, the original)."""
+    d = ra.example_scene("cornell-smoke", 1.0)
+    quads, media = d.quads, d.media.copy()
+    first = int(media["first"][0])
+    assert media["count"][0] == 6 and media["boundary"][0] == ra.RT_SURF_QUAD
+    extra = []
+    for side in range(4):  # front, right, back, left (make_box's order, surfaces.rs:549-578); top and bottom stay whole
+        q = quads[first + side].copy()
+        half = q["v"] / 2.0
+        lower, upper = q.copy(), q.copy()
+        lower["v"], upper["v"] = half, half
+        upper["q"] = q["q"] + half
+        for h in (lower, upper):
+            n = np.cross(h["u"], h["v"])
+            h["normal"], h["w"] = n / np.sqrt(n @ n), n / (n @ n)
+            h["d"] = h["normal"] @ h["q"]
+        # the very same planes, up to the last bits of a turned normal
+        assert np.allclose(lower["normal"], q["normal"], rtol=0, atol=1e-15) and abs(lower["d"] - q["d"]) + abs(upper["d"] - q["d"]) < 1e-12
+        extra += [lower, upper]
+    extra += [quads[first + 4].copy(), quads[first + 5].copy()]
+    more = np.concatenate([quads, np.array(extra, dtype=quads.dtype)])
+    media["first"][0], media["count"][0] = len(quads), 10
+    split = ra.SceneDesc.from_arrays(d.materials, d.spheres, d.triangles, more, d.surfaces, d.background, d.camera, media=media)
+    return split, d
+
+
+def test_medium_boundary_of_ten_quads_builds(ra, ref):
+    """A boundary of more than six quads is accepted (the reference's ConstantMedium takes any Hittable,
+    surfaces.rs:601-608), and oracle and product see the same scene."""
+    split, d = _smoke_with_split_sides(ra)
+    s = ra.Scene(split, ra.RT_DEVICE_NONE)
+    o = ref.RefScene.from_desc(split, CAMERAS["cornell-smoke"](1.0))
+    assert np.array_equal(s.leaf_order(), o.leaf_order()[0])
+    s.close()
+
+
+@pytest.mark.gpu
+def test_medium_boundary_of_ten_quads_renders_like_the_box_it_is(ra, ref):
+    """The ten-quad boundary encloses the same solid by the same planes, so a ray enters and leaves it at the very
+    same t (to the last bits of a turned normal) and the free-path draws fall the same way: the image is the six-quad
+    box's, bit for bit at one sample per pixel and up to the order of the additions at 25 — and within the usual bars of the oracle's image of the ten-quad scene."""
+    from test_gpu_parity import _check_image, _same_image
+
+    split, d = _smoke_with_split_sides(ra)
+    w = h = 96
+    a, b = ra.Scene(split, 0), ra.Scene(d, 0)
+    for sampler in (0, 1):
+        ia, _ = a.render(w, h, 5, sampler=sampler)
+        ib, _ = b.render(w, h, 5, sampler=sampler)
+        assert _same_image(ia, ib, 25)  # equal up to the order of the f32 additions into a pixel (atomics)
+        one_a, _ = a.render(w, h, 1, sampler=sampler)
+        one_b, _ = b.render(w, h, 1, sampler=sampler)
+        assert np.array_equal(one_a, one_b)  # one sample per pixel: no additions, the very same bits
+        want, _ = ref.RefScene.from_desc(split, CAMERAS["cornell-smoke"](1.0)).render(w, h, 5, threads=16, sampler=sampler)
+        _check_image(ia, want, 25, f"ten-quad medium, sampler {sampler}")
+    a.close(), b.close()
+
+
 def test_examples_camera_matches_oracle_and_unsupported_names_are_refused(ra, ref):
     for name, aspect in (("one-weekend", 1.5), ("cornell", 1.0), ("random-spheres", 1.5), ("two-spheres", 1.5),
                          ("two-perlin", 1.5), ("earth", 1.5), ("cornell-smoke", 1.0), ("final-scene", 1.0)):
