@@ -62,6 +62,7 @@ constexpr int kBlock = RT_BLOCK;
 #else
 #define RT_REGION(name) ((void)0)
 #endif
+constexpr int kPrioNode = 2, kPrioLeaf = 1;  // s_setprio levels of the node and leaf trips (everything else runs at 0)
 constexpr uint32_t kChunkStrata = 16;  // strata per chunk in the first phase (a chunk is 64 pixels x this many strata)
 constexpr int kPhases = 5;
 
@@ -323,9 +324,11 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
             // a few node visits per trip: amortises the stage selection over the dependent fetches of one descent.
             // A node trip is a chain of dependent fetches with little arithmetic between them: the wave goes first
             // at the issue arbiter while it runs one (s_setprio), so that its next fetch is on its way before the
-            // leaf and shade trips of the SIMD's other waves take their turn (teapot, dual +1.6 %, lucy +0.9 %; the
-            // shade stage first instead: -2.6 %; node and leaf stages both first: nothing).
-            __builtin_amdgcn_s_setprio(1);
+            // leaf and shade trips of the SIMD's other waves take their turn: lucy +3.3 %, teapot +3.8 %, cornell_lucy
+            // +2.7 %, dual +4.9 %.  Leaf trips go second (another +0.5 %), shade trips last; the shade stage first
+            // instead: -2.6 %; node and leaf stages at one level: +-0; only the fetch-issuing ends of the leaf and
+            // shade stages raised: +-0 (profiles/r3_experiments.md).
+            __builtin_amdgcn_s_setprio(kPrioNode);
             RT_REGION("node");
             if (SIX && __any(sp + RT_NODE_STEPS > (int)kLdsStackCap)) {  // a push or pop may pass the LDS levels
                 RT_REGION("node.deep");
@@ -346,10 +349,12 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(EXT, MEDIA, TREE, NOISE, SIX
             if (STATS) trips[1]++, lanes_on[1] += n_leaf, stage_run = 1;
             if (STATS && exhausted) drain_trips[1]++, drain_lanes[1] += n_leaf;
             RT_REGION("leaf");
+            __builtin_amdgcn_s_setprio(kPrioLeaf);
             if (node < 0) {
                 leaf_step<STATS, EXT, TREE>(sc, ray, sr, 0.001f, ~node, best, st);
                 node = (SIX && sp > (int)kLdsStackCap) ? stack_pop(deep_stack, sp) : stack_pop(stack, sp);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         stage = forget_uniform(stage);
         if (stage == 2) {
