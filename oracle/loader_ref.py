@@ -136,16 +136,16 @@ def read_obj_first_model(path):
                 toks = [t.split("/") for t in tok[1:]]
                 if len(toks) != 3:
                     raise ValueError("only triangles are supported")
-                faces.append([int(t[0]) for t in toks])
+                # 1-based, or negative = relative to the statements read SO FAR (tobj resolves an index where it parses the face)
+                faces.append([int(t[0]) - 1 if int(t[0]) > 0 else len(pos) + int(t[0]) for t in toks])
                 if len(toks[0]) == 3 and toks[0][2]:
-                    nfaces.append([int(t[2]) for t in toks])
+                    nfaces.append([int(t[2]) - 1 if int(t[2]) > 0 else len(nrm) + int(t[2]) for t in toks])
             elif key in ("o", "g") and faces:  # a bare `g` / `o` line too
                 break  # only the first model is used (load.rs:225-229)
     pos32 = np.array(pos, dtype=np.float32)  # numpy parses decimal -> f32 with correct rounding
 
     def first_use(ids, n):
         ids = np.array(ids, dtype=np.int64)
-        ids = np.where(ids < 0, ids + n, ids - 1)
         flat = ids.reshape(-1)
         _, first = np.unique(flat, return_index=True)
         order = flat[np.sort(first)]  # ids in order of first use (export_faces_multi_index)

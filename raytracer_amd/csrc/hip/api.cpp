@@ -475,18 +475,6 @@ uint32_t half_bits_up(uint32_t e) {
     return ((uint32_t)(top + 15) << 10) | mant;
 }
 
-// [0, n) in contiguous chunks on up to `max_tasks` threads (the caller's included); fn(begin, end) writes disjoint
-// elements.  Small ranges stay on the calling thread.
-template <class F>
-void parallel_chunks(size_t n, size_t min_chunk, size_t max_tasks, F&& fn) {
-    const size_t tasks = std::max<size_t>(1, std::min(max_tasks, n / std::max<size_t>(min_chunk, 1)));
-    if (tasks == 1) return fn((size_t)0, n);
-    std::vector<std::future<void>> jobs;
-    for (size_t t = 1; t < tasks; ++t) jobs.push_back(run_async([&fn, n, t, tasks]() { fn(n * t / tasks, n * (t + 1) / tasks); }));
-    fn((size_t)0, n / tasks);
-    for (auto& j : jobs) j.get();
-}
-
 // Render tree + loose list -> f32 arrays of the render kernels.
 void flatten_render(const rt_scene_desc& d, rt_scene& s) {
     const size_t n_surf = d.n_surfaces;

@@ -1,12 +1,34 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <future>
 #include <stdexcept>
 
 namespace rt {
+
+void TreePiece::lay_out(BvhNode* dst, int32_t base) const {
+    // the big attached pieces on threads of their own, the rest here
+    std::vector<std::future<void>> jobs;
+    for (const Attached& a : attached) {
+        if (a.piece->size >= 4096) jobs.push_back(run_async([&a, dst, base]() { a.piece->lay_out(dst, base + a.at); }));
+        else a.piece->lay_out(dst, base + a.at);
+    }
+    for (size_t i = 0; i < own.size(); ++i) {
+        BvhNode n = own[i];
+        if (!n.is_leaf()) n.left += base, n.right += base;
+        dst[base + pos[i]] = n;
+    }
+    for (auto& j : jobs) j.get();
+}
+
+void TreePiece::finish(Bvh& out) const {
+    out.nodes.resize((size_t)size);
+    lay_out(out.nodes.data(), 0);
+    out.max_depth = max_depth, out.max_leaf_size = max_leaf_size, out.n_leaves = n_leaves;
+}
 
 namespace {
 
@@ -22,31 +44,24 @@ const double kTraversalCost = 2.0;  // bvh.rs:18
 const size_t kMaxLeafSize = 8;      // bvh.rs:23
 
 // Subtrees are independent (disjoint ranges of `items`, sorted in place), so the top levels hand their left
-// child to another thread; each task builds into its own node array and the parent splices the arrays back in
-// the order a sequential build would have produced (self, left subtree, right subtree).
-constexpr size_t kParallelMin = 8192;   // smallest range worth a task
-constexpr uint32_t kParallelDepth = 4;  // levels that fork: at most 2^4 tasks
-
-int32_t splice(Bvh& dst, const Bvh& src) {
-    const int32_t base = (int32_t)dst.nodes.size();
-    for (BvhNode n : src.nodes) {
-        if (!n.is_leaf()) n.left += base, n.right += base;
-        dst.nodes.push_back(n);
-    }
-    dst.max_depth = std::max(dst.max_depth, src.max_depth);
-    dst.max_leaf_size = std::max(dst.max_leaf_size, src.max_leaf_size);
-    dst.n_leaves += src.n_leaves;
-    return base;
-}
+// child to another thread; each task builds into a piece of its own, which the parent attaches where a sequential
+// build would have produced its nodes (self, left subtree, right subtree): TreePiece.
+constexpr size_t kParallelMin = 2048;   // smallest range worth a task
+// Ranges of at least this many items are sorted by a team of threads: the one or two nodes at the very top, while
+// nothing else of this build runs.  (Further down, several nodes are in flight beside the render-tree build; two
+// teams at 40-60 000 items each then waited at their barriers for members that had no core: 5-7 ms a sort, not 1.5.)
+constexpr size_t kTeamSortMin = 65536;
+constexpr uint32_t kParallelDepth = 8;  // levels that fork (with kParallelMin: some fifty tasks on a 100 000-triangle mesh)
 
 struct Builder {
     std::vector<Item>& items;
-    std::vector<double> right_area;             // scratch for the sweep
-    std::vector<uint64_t> keys, keys_tmp;       // scratch for the sort
-    std::vector<uint32_t> perm, perm_tmp;
-    std::vector<Item> sorted;
-    Bvh* out = nullptr;
-    explicit Builder(std::vector<Item>& it, Bvh* o) : items(it), out(o) {}
+    // scratch (grown without being filled: every element is written before it is read)
+    std::vector<double, Uninit<double>> right_area;           // for the sweep
+    std::vector<uint64_t, Uninit<uint64_t>> keys, keys_tmp;  // for the sort
+    std::vector<uint32_t, Uninit<uint32_t>> perm, perm_tmp;
+    std::vector<Item, Uninit<Item>> sorted;
+    TreePiece* out = nullptr;
+    explicit Builder(std::vector<Item>& it, TreePiece* o) : items(it), out(o) {}
 
     // The reference's `surfaces.sort_by(|a, b| a.min[axis].partial_cmp(b.min[axis]))` (bvh.rs:209-218): a STABLE sort,
     // whose treatment of equal keys decides the tree.  Same result as std::stable_sort with `<` on the keys, three
@@ -60,6 +75,7 @@ struct Builder {
             return;
         }
         keys.resize(n), keys_tmp.resize(n), perm.resize(n), perm_tmp.resize(n), sorted.resize(n);
+        if (n >= kTeamSortMin) return team_sort_by_min(first, n, axis);
         uint64_t all_or = 0, all_and = ~0ull;
         for (size_t i = 0; i < n; ++i) {
             const double v = items[first + i].box.lo.get(axis) + 0.0;  // -0.0 + 0.0 == +0.0
@@ -85,17 +101,75 @@ struct Builder {
         std::copy(sorted.begin(), sorted.begin() + n, items.begin() + first);
     }
 
-    int32_t make_leaf(size_t first, size_t count, uint32_t depth) {
+    // (make_leaf and build return the node's index in the piece and leave its box in `box`)
+    // The same sort — the same digits, least significant first, each pass stable — for the ranges at the top of the
+    // tree, where it is all there is to do, on a team of threads: every member takes one run of the array, counts its
+    // run's digits, finds where its share of each bucket starts (after the smaller buckets and after the same bucket's
+    // items of the runs before it) and moves its items there in order.  A stable sort has one outcome: this one.
+    static uint64_t sort_key(double v) {
+        v += 0.0;  // -0.0 + 0.0 == +0.0
+        uint64_t u;
+        std::memcpy(&u, &v, 8);
+        return u ^ ((u >> 63) ? ~0ull : 0x8000000000000000ull);
+    }
+    void team_sort_by_min(size_t first, size_t n, int axis) {
+        const size_t members = std::min<size_t>(8, n / 16384);
+        std::vector<uint64_t> ors(members, 0), ands(members, ~0ull);
+        std::vector<std::array<uint32_t, 256>> counts(members);
+        run_team(members, [&](size_t m, Team& team) {
+            const auto [begin, end] = team.chunk(m, n);
+            uint64_t *k_in = keys.data(), *k_out = keys_tmp.data();  // every member swaps its own
+            uint32_t *p_in = perm.data(), *p_out = perm_tmp.data();
+            uint64_t my_or = 0, my_and = ~0ull;
+            for (size_t i = begin; i < end; ++i) {
+                const uint64_t u = sort_key(items[first + i].box.lo.get(axis));
+                k_in[i] = u, p_in[i] = (uint32_t)i;
+                my_or |= u, my_and &= u;
+            }
+            ors[m] = my_or, ands[m] = my_and;
+            team.barrier();
+            uint64_t all_or = 0, all_and = ~0ull;
+            for (size_t k = 0; k < team.members; ++k) all_or |= ors[k], all_and &= ands[k];
+            const uint64_t varies = all_or ^ all_and;  // bits that are not the same in every key
+            for (int shift = 0; shift < 64; shift += 8) {
+                if (((varies >> shift) & 0xffu) == 0) continue;
+                std::array<uint32_t, 256> mine{};
+                for (size_t i = begin; i < end; ++i) mine[(k_in[i] >> shift) & 0xffu]++;
+                counts[m] = mine;
+                team.barrier();
+                uint32_t at = 0;  // mine[b] becomes where this run's items of bucket b go
+                for (int b = 0; b < 256; ++b) {
+                    uint32_t before = 0, all = 0;
+                    for (size_t k = 0; k < team.members; ++k) {
+                        if (k < m) before += counts[k][b];
+                        all += counts[k][b];
+                    }
+                    mine[b] = at + before, at += all;
+                }
+                for (size_t i = begin; i < end; ++i) {
+                    const uint32_t dst = mine[(k_in[i] >> shift) & 0xffu]++;
+                    k_out[dst] = k_in[i], p_out[dst] = p_in[i];
+                }
+                team.barrier();  // (also: nobody writes counts[] for the next digit before everybody has read this one's)
+                std::swap(k_in, k_out), std::swap(p_in, p_out);
+            }
+            for (size_t i = begin; i < end; ++i) sorted[i] = items[first + p_in[i]];
+            team.barrier();
+            std::copy(sorted.begin() + begin, sorted.begin() + end, items.begin() + first + begin);
+        });
+    }
+
+    int32_t make_leaf(size_t first, size_t count, uint32_t depth, Aabb& box) {
         BvhNode n;
         n.box = Aabb::empty();  // bvh.rs:290-293
         for (size_t i = 0; i < count; ++i) n.box = n.box.merge(items[first + i].box);
         n.first = (int32_t)first;
         n.count = (int32_t)count;
-        out->nodes.push_back(n);
+        box = n.box;
         out->max_depth = std::max(out->max_depth, depth);
         out->max_leaf_size = std::max(out->max_leaf_size, (uint32_t)count);
         out->n_leaves++;
-        return (int32_t)out->nodes.size() - 1;
+        return out->push(n);
     }
 
     // SAHSplitStrategy::split_at, bvh.rs:131-174.  Returns 0 for "do not split".  The reference builds two arrays of
@@ -129,8 +203,8 @@ struct Builder {
     }
 
     // BVHNode::new_with_strategy, bvh.rs:183-234
-    int32_t build(size_t first, size_t n, uint32_t depth) {
-        if (n <= kMaxLeafSize) return make_leaf(first, n, depth);
+    int32_t build(size_t first, size_t n, uint32_t depth, Aabb& box) {
+        if (n <= kMaxLeafSize) return make_leaf(first, n, depth, box);
         V3 mins{INFINITY, INFINITY, INFINITY}, maxs{-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = 0; i < n; ++i) {
             V3 c = items[first + i].box.centroid();
@@ -143,29 +217,30 @@ struct Builder {
         if (span.get(axis) < span.get(2)) axis = 2;
         stable_sort_by_min(first, n, axis);
         size_t split = sah_split(first, n);
-        if (split == 0) return make_leaf(first, n, depth);
-        int32_t self = (int32_t)out->nodes.size();
-        out->nodes.emplace_back();
+        if (split == 0) return make_leaf(first, n, depth, box);
+        const size_t slot = out->own.size();
+        const int32_t self = out->push(BvhNode{});
         int32_t l, r;
+        Aabb lbox, rbox;
         if (depth <= kParallelDepth && split >= kParallelMin && n - split >= kParallelMin) {
-            Bvh left_tree, right_tree;
+            auto left_tree = std::make_unique<TreePiece>(), right_tree = std::make_unique<TreePiece>();
             auto left_job = run_async([&]() {
-                Builder b(items, &left_tree);
-                b.build(first, split, depth + 1);
+                Builder b(items, left_tree.get());
+                b.build(first, split, depth + 1, lbox);
             });
-            Builder b(items, &right_tree);
-            b.build(first + split, n - split, depth + 1);
+            Builder b(items, right_tree.get());
+            b.build(first + split, n - split, depth + 1, rbox);
             left_job.get();
-            l = splice(*out, left_tree);
-            r = splice(*out, right_tree);
+            l = out->attach(std::move(left_tree));
+            r = out->attach(std::move(right_tree));
         } else {
-            l = build(first, split, depth + 1);
-            r = build(first + split, n - split, depth + 1);
+            l = build(first, split, depth + 1, lbox);
+            r = build(first + split, n - split, depth + 1, rbox);
         }
-        BvhNode& node = out->nodes[self];
+        BvhNode& node = out->own[slot];
         node.left = l;
         node.right = r;
-        node.box = out->nodes[l].box.merge(out->nodes[r].box);
+        node.box = box = lbox.merge(rbox);
         return self;
     }
 };
@@ -282,10 +357,13 @@ struct Nested {
             items[i] = {member_box(tr.members[i]), tr.members[i]};
             tr.build_box = tr.build_box.merge(items[i].box);
         }
-        Builder b(items, &tr.t);
+        TreePiece piece;
+        Builder b(items, &piece);
         const bool one_leaf = g >= 0 ? d.groups[g].leaf != 0 : !d.use_bvh;
-        if (one_leaf) b.make_leaf(0, items.size(), 1);
-        else b.build(0, items.size(), 1);
+        Aabb box;
+        if (one_leaf) b.make_leaf(0, items.size(), 1, box);
+        else b.build(0, items.size(), 1, box);
+        piece.finish(tr.t);
         tr.t.order.resize(items.size());
         for (size_t i = 0; i < items.size(); ++i) tr.t.order[i] = items[i].id;
     }
@@ -394,13 +472,17 @@ void build_bvh(const rt_scene_desc& d, Bvh& out) {
         return;
     }
     std::vector<Item> items(d.n_surfaces);
-    for (size_t i = 0; i < d.n_surfaces; ++i) items[i] = {surface_bounds(d, d.surfaces[i]), (int32_t)i};
-    Builder b(items, &out);
-    out.nodes.reserve(d.n_surfaces / 2 + 16);
+    parallel_chunks(d.n_surfaces, 8192, 8, [&](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; ++i) items[i] = {surface_bounds(d, d.surfaces[i]), (int32_t)i};
+    });
+    TreePiece piece;
+    Builder b(items, &piece);
+    Aabb box;
     if (d.use_bvh)
-        b.build(0, d.n_surfaces, 1);
+        b.build(0, d.n_surfaces, 1, box);
     else
-        b.make_leaf(0, d.n_surfaces, 1);
+        b.make_leaf(0, d.n_surfaces, 1, box);
+    piece.finish(out);
     out.order.resize(d.n_surfaces);
     for (size_t i = 0; i < d.n_surfaces; ++i) out.order[i] = items[i].id;
 }

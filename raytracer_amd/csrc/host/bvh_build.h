@@ -4,6 +4,7 @@
 // sequence that decides equal-t ties in the reference traversal (bvh.rs:272-273, 308).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "../../../include/rt.h"
@@ -34,6 +35,41 @@ struct Bvh {
     // node array itself is then deeper by the chains: `flat_depth` (0: same as max_depth).
     uint32_t flat_depth = 0;
     size_t ref_nodes = 0;  // nodes as the reference counts them (0: nodes.size())
+};
+
+// Where a build puts its nodes.  The top levels of both builders hand one child to another thread, and every task
+// builds into a piece of its own; a piece that was built elsewhere is ATTACHED where a sequential build would have
+// laid its nodes (self, left subtree, right subtree), i.e. it takes its range of indices, and its nodes are copied
+// once, at the end, into the one array (lay_out, big pieces on threads of their own).  Indices inside a piece count
+// from the piece's first node.  (The pieces used to be copied into their parent at every join: a node of lucy's
+// tree was copied four times, the last copies on one thread while the others had ended — 6 of the render tree's 19 ms.)
+struct TreePiece {
+    std::vector<BvhNode> own;  // the nodes this task made, in the order it made them
+    std::vector<int32_t> pos;  // own[i]'s index in the piece
+    struct Attached {
+        int32_t at;
+        std::unique_ptr<TreePiece> piece;
+    };
+    std::vector<Attached> attached;
+    int32_t size = 0;  // nodes of the piece, attached pieces included
+    uint32_t max_depth = 0, max_leaf_size = 0, n_leaves = 0;
+
+    // the index of the new node; own.back() is the node (the caller keeps own.size() - 1 to come back to it)
+    int32_t push(const BvhNode& n) {
+        own.push_back(n), pos.push_back(size);
+        return size++;
+    }
+    int32_t attach(std::unique_ptr<TreePiece> p) {
+        const int32_t at = size;
+        size += p->size;
+        max_depth = std::max(max_depth, p->max_depth), max_leaf_size = std::max(max_leaf_size, p->max_leaf_size);
+        n_leaves += p->n_leaves;
+        attached.push_back({at, std::move(p)});
+        return at;
+    }
+    void lay_out(BvhNode* dst, int32_t base) const;
+    // the finished tree: nodes in `out.nodes` (root first), the figures in `out`
+    void finish(Bvh& out) const;
 };
 
 // Bounding box of one surface: surfaces.rs:57-69 (sphere), 281-291 (triangle), 356-359 (quad).

@@ -9,6 +9,7 @@
 #include <stdexcept>
 
 #include "scene_host.h"
+#include "worker.h"
 #include "yaml_lite.h"
 
 namespace rt {
@@ -232,19 +233,21 @@ void load_mesh(const std::string& path, const std::vector<Transform>& ts, int ma
                  std::to_string(verts.size()) + "); the reference indexes normals by vertex index (surfaces.rs:231-243)");
     }
 
-    size_t ntri = obj.indices.size() / 3;
-    out.triangles.reserve(out.triangles.size() + ntri);
-    for (size_t t = 0; t < ntri; ++t) {
-        rt_triangle tri{};
-        for (int k = 0; k < 3; ++k) {
-            uint32_t idx = obj.indices[3 * t + k];
-            v3out(tri.v[k], verts[idx]);
-            v3out(tri.n[k], normals[idx]);
+    const size_t ntri = obj.indices.size() / 3, tri_base = out.triangles.size(), surf_base = out.surfaces.size();
+    out.triangles.resize(tri_base + ntri), out.surfaces.resize(surf_base + ntri);  // (not filled: DefaultInit)
+    parallel_chunks(ntri, 8192, 8, [&](size_t begin, size_t end) {
+        for (size_t t = begin; t < end; ++t) {
+            rt_triangle tri{};
+            for (int k = 0; k < 3; ++k) {
+                uint32_t idx = obj.indices[3 * t + k];
+                v3out(tri.v[k], verts[idx]);
+                v3out(tri.n[k], normals[idx]);
+            }
+            tri.material = mat;
+            out.surfaces[surf_base + t] = {RT_SURF_TRIANGLE, (int32_t)(tri_base + t)};
+            out.triangles[tri_base + t] = tri;
         }
-        tri.material = mat;
-        out.surfaces.push_back({RT_SURF_TRIANGLE, (int32_t)out.triangles.size()});
-        out.triangles.push_back(tri);
-    }
+    });
 }
 
 std::string dirname_of(const std::string& p) {

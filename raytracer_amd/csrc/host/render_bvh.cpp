@@ -14,6 +14,7 @@ namespace {
 
 constexpr int kBins = 32;
 constexpr size_t kParallelBinMin = 32768;  // nodes of at least this many items bin them on several threads
+constexpr size_t kTeamPartitionMin = 65536;  // ... and partition them on a team (the root, mostly: see kTeamSortMin in bvh_build.cpp)
 constexpr size_t kSmallNode = 16;  // nodes of at most this many items find their split without the bin arrays
 constexpr double kIntersectCost = 1.0;
 
@@ -31,27 +32,17 @@ double area(const Aabb& b) {
 
 constexpr uint32_t kBalancedFromDepth = 32;  // root = 1; 32 + log2(2^24 primitives) = 56 = the kernels' stack
 
-constexpr size_t kParallelMin = 8192;   // as in bvh_build.cpp: the top levels fork their left child
-constexpr uint32_t kParallelDepth = 4;
+constexpr size_t kParallelMin = 2048;   // as in bvh_build.cpp: the top levels fork their left child
+constexpr uint32_t kParallelDepth = 8;
 
-int32_t splice(Bvh& dst, const Bvh& src) {
-    const int32_t base = (int32_t)dst.nodes.size();
-    for (BvhNode n : src.nodes) {
-        if (!n.is_leaf()) n.left += base, n.right += base;
-        dst.nodes.push_back(n);
-    }
-    dst.max_depth = std::max(dst.max_depth, src.max_depth);
-    dst.max_leaf_size = std::max(dst.max_leaf_size, src.max_leaf_size);
-    dst.n_leaves += src.n_leaves;
-    return base;
-}
+using Items = std::vector<Item, Uninit<Item>>;
 
 struct RBuilder {
-    std::vector<Item>& items;
-    Bvh* out;
+    Items& items;
+    TreePiece* out;
     uint32_t max_leaf;
     double traversal_cost;  // relative to one primitive test
-    RBuilder(std::vector<Item>& it, Bvh* o, uint32_t ml, double ct) : items(it), out(o), max_leaf(ml), traversal_cost(ct) {}
+    RBuilder(Items& it, TreePiece* o, uint32_t ml, double ct) : items(it), out(o), max_leaf(ml), traversal_cost(ct) {}
 
     struct Bounds {
         Aabb box = Aabb::empty();  // of the items' boxes
@@ -67,26 +58,26 @@ struct RBuilder {
         return b;
     }
 
-    // both subtrees of the node `self` (already pushed); [first, mid) and [mid, first + n), with their bounds
-    void children(int32_t self, const Aabb& box, size_t first, size_t mid, size_t n, const Bounds& lb, const Bounds& rb,
+    // both subtrees of the node in own[slot] (already pushed); [first, mid) and [mid, first + n), with their bounds
+    void children(size_t slot, const Aabb& box, size_t first, size_t mid, size_t n, const Bounds& lb, const Bounds& rb,
                   uint32_t depth) {
         int32_t l, r;
         if (depth <= kParallelDepth && mid - first >= kParallelMin && first + n - mid >= kParallelMin) {
-            Bvh left_tree, right_tree;
+            auto left_tree = std::make_unique<TreePiece>(), right_tree = std::make_unique<TreePiece>();
             auto left_job = run_async([&]() {
-                RBuilder b(items, &left_tree, max_leaf, traversal_cost);
+                RBuilder b(items, left_tree.get(), max_leaf, traversal_cost);
                 b.build(first, mid - first, lb, depth + 1);
             });
-            RBuilder b(items, &right_tree, max_leaf, traversal_cost);
+            RBuilder b(items, right_tree.get(), max_leaf, traversal_cost);
             b.build(mid, first + n - mid, rb, depth + 1);
             left_job.get();
-            l = splice(*out, left_tree);
-            r = splice(*out, right_tree);
+            l = out->attach(std::move(left_tree));
+            r = out->attach(std::move(right_tree));
         } else {
             l = build(first, mid - first, lb, depth + 1);
             r = build(mid, first + n - mid, rb, depth + 1);
         }
-        BvhNode& node = out->nodes[self];
+        BvhNode& node = out->own[slot];
         node.left = l, node.right = r, node.box = box;
     }
 
@@ -94,11 +85,52 @@ struct RBuilder {
         BvhNode node;
         node.box = box;
         node.first = (int32_t)first, node.count = (int32_t)n;
-        out->nodes.push_back(node);
         out->max_depth = std::max(out->max_depth, depth);
         out->max_leaf_size = std::max(out->max_leaf_size, (uint32_t)n);
         out->n_leaves++;
-        return (int32_t)out->nodes.size() - 1;
+        return out->push(node);
+    }
+
+    // The partition of a node at the top of the tree, where it is all there is to do, on a team of threads: every
+    // member counts the items of its run that go left and gathers both sides' bounds, then moves its items to their
+    // places in a second array — the left ones of all runs first, run by run, then the right ones — and copies its
+    // share back.  Stable, so the outcome does not depend on how many threads there are.  Returns the left count.
+    template <class Pred>
+    size_t partition_on_a_team(size_t first, size_t n, Pred&& goes_left, Bounds& lb, Bounds& rb) {
+        const size_t members = std::min<size_t>(8, n / 16384);
+        Items moved(n);
+        std::vector<size_t> lefts(members, 0);
+        std::vector<Bounds> lbs(members), rbs(members);
+        std::vector<uint8_t, Uninit<uint8_t>> side(n);
+        run_team(members, [&](size_t m, Team& team) {
+            const auto [begin, end] = team.chunk(m, n);
+            Bounds my_lb, my_rb;
+            size_t my_left = 0;
+            for (size_t i = begin; i < end; ++i) {
+                const Item& item = items[first + i];
+                const bool left = goes_left(item);
+                side[i] = left, my_left += left;
+                (left ? my_lb : my_rb).add(item);
+            }
+            lefts[m] = my_left, lbs[m] = my_lb, rbs[m] = my_rb;
+            team.barrier();
+            size_t all_left = 0, l = 0, r = 0;  // l, r: left / right items of the runs before this one
+            for (size_t k = 0; k < team.members; ++k) {
+                all_left += lefts[k];
+                if (k < m) l += lefts[k], r += team.chunk(k, n).second - team.chunk(k, n).first - lefts[k];
+            }
+            r += all_left;
+            for (size_t i = begin; i < end; ++i) moved[side[i] ? l++ : r++] = items[first + i];
+            team.barrier();
+            std::copy(moved.begin() + begin, moved.begin() + end, items.begin() + first + begin);
+        });
+        size_t all_left = 0;
+        for (size_t k = 0; k < members; ++k) {
+            all_left += lefts[k];
+            lb.box = lb.box.merge(lbs[k].box), lb.cb = lb.cb.merge(lbs[k].cb);
+            rb.box = rb.box.merge(rbs[k].box), rb.cb = rb.cb.merge(rbs[k].cb);
+        }
+        return all_left;
     }
 
     // A node's bounds come down from its parent, which gathered them while it partitioned its items (the
@@ -119,9 +151,9 @@ struct RBuilder {
             const size_t mid = first + n / 2;
             std::nth_element(items.begin() + first, items.begin() + mid, items.begin() + first + n,
                              [axis](const Item& a, const Item& b) { return a.c.get(axis) < b.c.get(axis); });
-            const int32_t self = (int32_t)out->nodes.size();
-            out->nodes.emplace_back();
-            children(self, box, first, mid, n, bounds_of(first, mid - first), bounds_of(mid, first + n - mid), depth);
+            const size_t slot = out->own.size();
+            const int32_t self = out->push(BvhNode{});
+            children(slot, box, first, mid, n, bounds_of(first, mid - first), bounds_of(mid, first + n - mid), depth);
             return self;
         }
 
@@ -238,19 +270,26 @@ struct RBuilder {
             mid = first + n / 2;  // coincident centroids: split by position in the list
         } else {
             const double blo = lo[best_axis], bscale = scale[best_axis];
-            auto it = std::partition(items.begin() + first, items.begin() + first + n, [&](const Item& item) {
-                const bool left = std::min(kBins - 1, (int)((item.c.get(best_axis) - blo) * bscale)) <= best_bin;
-                (left ? lb : rb).add(item);  // the predicate is called once per item
-                return left;
-            });
-            mid = (size_t)(it - items.begin());
+            auto goes_left = [&](const Item& item) {
+                return std::min(kBins - 1, (int)((item.c.get(best_axis) - blo) * bscale)) <= best_bin;
+            };
+            if (n >= kTeamPartitionMin) {
+                mid = first + partition_on_a_team(first, n, goes_left, lb, rb);
+            } else {
+                auto it = std::partition(items.begin() + first, items.begin() + first + n, [&](const Item& item) {
+                    const bool left = goes_left(item);
+                    (left ? lb : rb).add(item);  // the predicate is called once per item
+                    return left;
+                });
+                mid = (size_t)(it - items.begin());
+            }
             have_bounds = true;
             if (mid == first || mid == first + n) mid = first + n / 2, have_bounds = false;
         }
         if (!have_bounds) lb = bounds_of(first, mid - first), rb = bounds_of(mid, first + n - mid);
-        const int32_t self = (int32_t)out->nodes.size();
-        out->nodes.emplace_back();
-        children(self, box, first, mid, n, lb, rb, depth);
+        const size_t slot = out->own.size();
+        const int32_t self = out->push(BvhNode{});
+        children(slot, box, first, mid, n, lb, rb, depth);
         return self;
     }
 };
@@ -259,16 +298,35 @@ struct RBuilder {
 
 void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, double traversal_cost, Bvh& out) {
     out = Bvh{};
-    std::vector<Item> items(ids.size());
-    RBuilder b(items, &out, std::max(1u, max_leaf), traversal_cost);
-    for (size_t i = 0; i < ids.size(); ++i) {
-        // the reference's box is inverted for a negative radius and too small for some quads: real bounds here,
-        // padded like the reference pads its (possibly flat) quad boxes
-        const Aabb fixed = true_bounds(d, d.surfaces[ids[i]]).pad(d.surfaces[ids[i]].type == RT_SURF_QUAD ? 0.0001 : 0.0);
-        items[i] = {fixed, 0.5 * (fixed.lo + fixed.hi), ids[i]};
+    Items items(ids.size());  // (filled below, in runs, by the threads that then own the pages)
+    TreePiece piece;
+    RBuilder b(items, &piece, std::max(1u, max_leaf), traversal_cost);
+    // (the node array's pages are touched for the first time beside the build, not after it: at most 2n - 1 nodes)
+    auto node_room = run_async([&]() { out.nodes.resize(2 * ids.size()); });
+    constexpr size_t kChunks = 8;
+    RBuilder::Bounds part[kChunks];
+    std::atomic<size_t> next_part{0};
+    parallel_chunks(ids.size(), 8192, kChunks, [&](size_t begin, size_t end) {
+        RBuilder::Bounds mine;
+        for (size_t i = begin; i < end; ++i) {
+            // the reference's box is inverted for a negative radius and too small for some quads: real bounds here,
+            // padded like the reference pads its (possibly flat) quad boxes
+            const Aabb fixed = true_bounds(d, d.surfaces[ids[i]]).pad(d.surfaces[ids[i]].type == RT_SURF_QUAD ? 0.0001 : 0.0);
+            items[i] = {fixed, 0.5 * (fixed.lo + fixed.hi), ids[i]};
+            mine.add(items[i]);
+        }
+        part[next_part.fetch_add(1)] = mine;
+    });
+    RBuilder::Bounds all;
+    for (const RBuilder::Bounds& p : part) all.box = all.box.merge(p.box), all.cb = all.cb.merge(p.cb);
+    try {
+        if (!ids.empty()) b.build(0, ids.size(), all, 1);
+    } catch (...) {
+        node_room.wait();
+        throw;
     }
-    out.nodes.reserve(ids.size());
-    if (!ids.empty()) b.build(0, ids.size(), b.bounds_of(0, ids.size()), 1);
+    node_room.get();
+    piece.finish(out);
     out.order.resize(ids.size());
     for (size_t i = 0; i < ids.size(); ++i) out.order[i] = items[i].id;
 }

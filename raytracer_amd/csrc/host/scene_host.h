@@ -1,5 +1,6 @@
 // Host-side scene ownership: the vectors behind an rt_scene_desc, plus the loader entry point.
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -8,15 +9,34 @@
 
 namespace rt {
 
+// resize() of a vector with this allocator leaves new elements of a plain C struct as they are (no zero fill): a
+// mesh's triangles are then written once, by the threads that fill them, instead of twice with the first on one thread.
+template <class T>
+struct DefaultInit : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInit<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U* p) noexcept {
+        ::new ((void*)p) U;
+    }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+
 // Owns the arrays an rt_scene_desc points at.  `desc` must stay the first member: rt_load_scene hands
 // out &desc and rt_scene_desc_free casts it back.
 struct HostScene {
     rt_scene_desc desc{};
     std::vector<rt_material> materials;
     std::vector<rt_sphere> spheres;
-    std::vector<rt_triangle> triangles;
+    std::vector<rt_triangle, DefaultInit<rt_triangle>> triangles;
     std::vector<rt_quad> quads;
-    std::vector<rt_surface_ref> surfaces;
+    std::vector<rt_surface_ref, DefaultInit<rt_surface_ref>> surfaces;
     std::vector<rt_medium> media;
     std::vector<rt_perlin> perlin;
     std::vector<rt_image> images;

@@ -10,8 +10,14 @@
 //    process silently.
 #pragma once
 #include <cstdint>
+#include <algorithm>
+#include <atomic>
+#include <cstddef>
 #include <future>
+#include <memory>
+#include <thread>
 #include <utility>
+#include <vector>
 
 namespace rt {
 
@@ -40,6 +46,81 @@ auto run_async(F&& f) {
         AltSignalStack alt;
         return fn();
     });
+}
+
+// resize(n) / a sized constructor of a vector with this allocator leave the new elements' memory as it is — for
+// arrays of plain data that the next loop fills on several threads (the first touch of the pages included), where
+// value-initialising them first would be one more pass, on one thread.  Every element must be assigned before it is read.
+template <class T>
+struct Uninit : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = Uninit<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U*) noexcept {}
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+
+// [0, n) in contiguous chunks on up to `max_tasks` threads (the caller's included); fn(begin, end) writes disjoint
+// elements.  Small ranges stay on the calling thread.
+template <class F>
+void parallel_chunks(size_t n, size_t min_chunk, size_t max_tasks, F&& fn) {
+    const size_t tasks = std::max<size_t>(1, std::min(max_tasks, n / std::max<size_t>(min_chunk, 1)));
+    if (tasks == 1) return fn((size_t)0, n);
+    std::vector<std::future<void>> jobs;
+    for (size_t t = 1; t < tasks; ++t) jobs.push_back(run_async([&fn, n, t, tasks]() { fn(n * t / tasks, n * (t + 1) / tasks); }));
+    fn((size_t)0, n / tasks);
+    for (auto& j : jobs) j.get();
+}
+
+// A team of threads (the caller is member 0) that runs fn(member, team) and meets at team.barrier() between the
+// phases of one piece of work: the top-level sort and partition of the tree builds, whose phases are too short to
+// start threads for each of them.  A member waiting at the barrier spins briefly, then yields.
+struct Team {
+    size_t members;
+    explicit Team(size_t n) : members(n) {}
+    void barrier() {
+        const uint32_t phase = phase_.load(std::memory_order_acquire);
+        if (arrived_.fetch_add(1, std::memory_order_acq_rel) + 1 == members) {
+            arrived_.store(0, std::memory_order_relaxed);
+            phase_.store(phase + 1, std::memory_order_release);
+            return;
+        }
+        for (uint32_t spins = 0; phase_.load(std::memory_order_acquire) == phase; ++spins)
+            if (spins > 256) std::this_thread::yield();
+    }
+    // [0, n) in `members` contiguous chunks: member m's
+    std::pair<size_t, size_t> chunk(size_t m, size_t n) const { return {n * m / members, n * (m + 1) / members}; }
+
+  private:
+    std::atomic<uint32_t> arrived_{0}, phase_{0};
+};
+template <class F>
+void run_team(size_t members, F&& fn) {
+    Team team(std::max<size_t>(members, 1));
+    // the members start their work together or not at all: one that could not be started would be waited for at
+    // the first barrier for ever
+    std::atomic<int> go{-1};  // -1: wait, 0: leave, 1: run
+    std::vector<std::future<void>> jobs;
+    try {
+        for (size_t m = 1; m < team.members; ++m)
+            jobs.push_back(run_async([&fn, &team, &go, m]() {
+                while (go.load(std::memory_order_acquire) < 0) std::this_thread::yield();
+                if (go.load(std::memory_order_acquire) == 1) fn(m, team);
+            }));
+    } catch (...) {
+        go.store(0, std::memory_order_release);
+        for (auto& j : jobs) j.wait();
+        throw;
+    }
+    go.store(1, std::memory_order_release);
+    fn((size_t)0, team);
+    for (auto& j : jobs) j.get();
 }
 
 }  // namespace rt

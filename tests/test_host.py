@@ -178,6 +178,71 @@ def test_obj_parsing(ra, tmp_path):
         ra.load_scene(_write(tmp_path, text.replace("m.obj", "quad.obj")), 1.0)
 
 
+def _long_obj(n_faces=30000, second_model_at=None, bad_line_at=None):
+    """An OBJ of `n_faces` triangles in well over three 256 KB blocks of text, vertices and faces interleaved, indices
+    absolute and relative by turns, comments and `vt` lines in between; optionally an object statement (and a second
+    model after it) or a malformed vertex at a given face."""
+    rng = np.random.default_rng(11)
+    lines, n_v = ["# long mesh", "o long", "g part"], 0
+    for f in range(n_faces):
+        if f == second_model_at:
+            lines.append("o second")
+        pts = rng.uniform(-3, 3, (3, 3))
+        for k, p in enumerate(pts):
+            lines.append("v %.9g %.9g %.9g" % tuple(p) if not (f == bad_line_at and k == 1) else "v 1.0 oops 2.0")
+        n_v += 3
+        if f % 7 == 0:
+            lines.append("vt 0.5 0.5")
+        if f % 11 == 0:
+            lines.append("# face %d" % f)
+        # a corner of some earlier face every now and then, so that blocks refer back across their borders
+        far = 1 + int(rng.integers(0, n_v - 2)) if f % 5 == 0 else n_v - 2
+        lines.append("f %d %d %d" % (far, n_v - 1, n_v) if f % 2 else "f %d -2 -1" % (far - n_v - 1))
+    return "\n".join(lines) + "\n"
+
+
+def test_obj_blocks_parsed_beside_the_inflater_match_the_independent_loader(ra, tmp_path):
+    """The reader parses a large file block by block while it is being inflated (obj_reader.cpp): relative indices,
+    line numbers and the first model's end must come out as if the file had been read line by line — checked against
+    oracle/loader_ref.py's sequential reader, gzipped and plain, with the second model starting in a late block."""
+    import gzip
+    text = CAM + ("scene:\n  background: [0,0,0]\n  surfaces:\n    - type: mesh\n      path: m.obj\n"
+                  "      material: {type: lambertian, albedo: [1,1,1]}\n")
+    wants = {}
+    for second in (None, 26000):
+        obj = _long_obj(second_model_at=second)
+        assert len(obj) > 4 * (256 << 10)
+        (tmp_path / "m.obj").write_text(obj)
+        (tmp_path / "m.obj.gz").write_bytes(gzip.compress(obj.encode(), 6))
+        want = loader_ref.load_scene(_write(tmp_path, text), 1.0).triangles
+        assert len(want) == (second or 30000)
+        wants[second] = want
+        for name in ("m.obj", "m.obj.gz"):
+            got = ra.load_scene(_write(tmp_path, text.replace("m.obj", name)), 1.0).triangles
+            assert len(got) == len(want), name
+            assert np.array_equal(got["v"].reshape(-1, 9), want[:, :9]), name
+            assert np.array_equal(got["n"].reshape(-1, 9), want[:, 9:18]), name
+    # two gzip members in one file (the trailer then understates the size) read as one text
+    obj = _long_obj()
+    half = obj.index("\n", len(obj) // 2) + 1
+    (tmp_path / "m.obj.gz").write_bytes(gzip.compress(obj[:half].encode()) + gzip.compress(obj[half:].encode()))
+    got = ra.load_scene(_write(tmp_path, text.replace("m.obj", "m.obj.gz")), 1.0).triangles
+    assert len(got) == 30000 and np.array_equal(got["v"].reshape(-1, 9), wants[None][:, :9])
+    # a malformed line in a late block is reported with its line number in the file; after the first model's end it is not read
+    bad = _long_obj(bad_line_at=25000)
+    line = 1 + bad[:bad.index("oops")].count("\n")
+    (tmp_path / "m.obj").write_text(bad)
+    with pytest.raises(ra.api.RtError, match=r"bad 'v' at line %d\b" % line):
+        ra.load_scene(_write(tmp_path, text), 1.0)
+    (tmp_path / "m.obj").write_text(_long_obj(second_model_at=20000, bad_line_at=25000))
+    assert len(ra.load_scene(_write(tmp_path, text), 1.0).triangles) == 20000
+    # a truncated gzip file is an error, not a shorter mesh
+    whole = gzip.compress(obj.encode())
+    (tmp_path / "m.obj.gz").write_bytes(whole[: len(whole) // 2])
+    with pytest.raises(ra.api.RtError, match="could not read"):
+        ra.load_scene(_write(tmp_path, text.replace("m.obj", "m.obj.gz")), 1.0)
+
+
 def test_obj_bare_group_line_ends_the_first_model(ra, tmp_path):
     """tobj finds the keyword with split_whitespace: a bare `g` (or `o`) line — `g\\r\\n` in a CRLF file included — is
     an object/group statement, so after a face it ends the first model (load.rs:225-229 uses the first model only).
