@@ -75,7 +75,12 @@ struct Builder {
             return;
         }
         keys.resize(n), keys_tmp.resize(n), perm.resize(n), perm_tmp.resize(n), sorted.resize(n);
-        if (n >= kTeamSortMin) return team_sort_by_min(first, n, axis);
+        if (n >= kTeamSortMin) {
+            try {
+                return team_sort_by_min(first, n, axis);
+            } catch (const std::system_error&) {  // no threads to be had: the same sort on this one
+            }
+        }
         uint64_t all_or = 0, all_and = ~0ull;
         for (size_t i = 0; i < n; ++i) {
             const double v = items[first + i].box.lo.get(axis) + 0.0;  // -0.0 + 0.0 == +0.0
@@ -224,13 +229,15 @@ struct Builder {
         Aabb lbox, rbox;
         if (depth <= kParallelDepth && split >= kParallelMin && n - split >= kParallelMin) {
             auto left_tree = std::make_unique<TreePiece>(), right_tree = std::make_unique<TreePiece>();
-            auto left_job = run_async([&]() {
-                Builder b(items, left_tree.get());
-                b.build(first, split, depth + 1, lbox);
-            });
-            Builder b(items, right_tree.get());
-            b.build(first + split, n - split, depth + 1, rbox);
-            left_job.get();
+            fork_join(
+                [&]() {
+                    Builder b(items, left_tree.get());
+                    b.build(first, split, depth + 1, lbox);
+                },
+                [&]() {
+                    Builder b(items, right_tree.get());
+                    b.build(first + split, n - split, depth + 1, rbox);
+                });
             l = out->attach(std::move(left_tree));
             r = out->attach(std::move(right_tree));
         } else {

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <functional>
 #include <stdexcept>
+#include <system_error>
 #include <future>
 #include <thread>
 
@@ -266,7 +267,11 @@ void load_obj_first_model(const std::string& path, ObjMesh& out) {
                 const char* text = source.text.data();
                 if (last) return parse_block(text, begin, end, *run);  // nothing left to overlap it with
                 if (jobs.size() - joined >= kInFlight) jobs[joined++].get();
-                jobs.push_back(run_async([text, begin, end, run]() { parse_block(text, begin, end, *run); }));
+                try {
+                    jobs.push_back(run_async([text, begin, end, run]() { parse_block(text, begin, end, *run); }));
+                } catch (const std::system_error&) {  // no thread to be had: parse it here
+                    parse_block(text, begin, end, *run);
+                }
             },
             join_all);
     } catch (...) {

@@ -64,13 +64,15 @@ struct RBuilder {
         int32_t l, r;
         if (depth <= kParallelDepth && mid - first >= kParallelMin && first + n - mid >= kParallelMin) {
             auto left_tree = std::make_unique<TreePiece>(), right_tree = std::make_unique<TreePiece>();
-            auto left_job = run_async([&]() {
-                RBuilder b(items, left_tree.get(), max_leaf, traversal_cost);
-                b.build(first, mid - first, lb, depth + 1);
-            });
-            RBuilder b(items, right_tree.get(), max_leaf, traversal_cost);
-            b.build(mid, first + n - mid, rb, depth + 1);
-            left_job.get();
+            fork_join(
+                [&]() {
+                    RBuilder b(items, left_tree.get(), max_leaf, traversal_cost);
+                    b.build(first, mid - first, lb, depth + 1);
+                },
+                [&]() {
+                    RBuilder b(items, right_tree.get(), max_leaf, traversal_cost);
+                    b.build(mid, first + n - mid, rb, depth + 1);
+                });
             l = out->attach(std::move(left_tree));
             r = out->attach(std::move(right_tree));
         } else {
@@ -224,8 +226,13 @@ struct RBuilder {
                 const size_t parts = std::min<size_t>(8, n / (kParallelBinMin / 4));
                 std::vector<Bins> part(parts);
                 std::vector<std::future<void>> jobs;
-                for (size_t t = 1; t < parts; ++t)
-                    jobs.push_back(run_async([&, t]() { bin_range(first + n * t / parts, first + n * (t + 1) / parts, part[t]); }));
+                for (size_t t = 1; t < parts; ++t) {
+                    try {
+                        jobs.push_back(run_async([&, t]() { bin_range(first + n * t / parts, first + n * (t + 1) / parts, part[t]); }));
+                    } catch (const std::system_error&) {  // no thread to be had: this run here
+                        bin_range(first + n * t / parts, first + n * (t + 1) / parts, part[t]);
+                    }
+                }
                 bin_range(first, first + n / parts, part[0]);
                 for (auto& j : jobs) j.get();
                 for (const Bins& p : part)
@@ -273,10 +280,22 @@ struct RBuilder {
             auto goes_left = [&](const Item& item) {
                 return std::min(kBins - 1, (int)((item.c.get(best_axis) - blo) * bscale)) <= best_bin;
             };
+            bool done = false;
             if (n >= kTeamPartitionMin) {
-                mid = first + partition_on_a_team(first, n, goes_left, lb, rb);
-            } else {
-                auto it = std::partition(items.begin() + first, items.begin() + first + n, [&](const Item& item) {
+                try {
+                    mid = first + partition_on_a_team(first, n, goes_left, lb, rb);
+                    done = true;
+                } catch (const std::system_error&) {  // no threads to be had: partition on this one
+                    lb = Bounds{}, rb = Bounds{};
+                }
+            }
+            if (!done) {
+                // (the big nodes keep their items in order, team or no team, so that the tree does not depend on it)
+                auto split = [&](auto&& pred) {
+                    return n >= kTeamPartitionMin ? std::stable_partition(items.begin() + first, items.begin() + first + n, pred)
+                                                  : std::partition(items.begin() + first, items.begin() + first + n, pred);
+                };
+                auto it = split([&](const Item& item) {
                     const bool left = goes_left(item);
                     (left ? lb : rb).add(item);  // the predicate is called once per item
                     return left;

@@ -22,6 +22,17 @@ BuildKnobs BuildKnobs::from_environment() {
 }
 
 namespace {
+std::atomic<int> g_forked_tasks{0};
+}  // namespace
+
+ForkSlot::ForkSlot() : taken(g_forked_tasks.fetch_add(1, std::memory_order_acq_rel) < kMaxForkedTasks) {
+    if (!taken) g_forked_tasks.fetch_sub(1, std::memory_order_acq_rel);
+}
+ForkSlot::~ForkSlot() {
+    if (taken) g_forked_tasks.fetch_sub(1, std::memory_order_acq_rel);
+}
+
+namespace {
 
 constexpr size_t kAltStackBytes = 1 << 16;
 bool g_trace_on = false;  // written once, at library load

@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <future>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -48,6 +49,40 @@ auto run_async(F&& f) {
     });
 }
 
+// How many forked tasks of the tree builds may be alive in this process at a time (both trees together).  A fork
+// beyond it — or one whose thread cannot be started — is simply not made: the parent builds that child itself, and
+// the tree is the same either way.  (Eight ranks on one node each build their scene; a process that started a
+// thread for every subtree of 2 048 items would hold a hundred of them against the node's task limit.)
+constexpr int kMaxForkedTasks = 24;
+struct ForkSlot {
+    bool taken;
+    ForkSlot();   // takes a slot if one is free
+    ~ForkSlot();  // gives it back
+    ForkSlot(const ForkSlot&) = delete;
+    ForkSlot& operator=(const ForkSlot&) = delete;
+};
+// `child` on a thread of its own if a slot is free and the thread starts, else here and now; then `rest` here; both
+// done when it returns.
+template <class Child, class Rest>
+void fork_join(Child&& child, Rest&& rest) {
+    ForkSlot slot;
+    std::future<void> job;
+    if (slot.taken) {
+        try {
+            job = run_async([&child]() { child(); });
+        } catch (const std::system_error&) {  // no thread to be had: not an error, just no fork
+        }
+    }
+    if (!job.valid()) child();
+    try {
+        rest();
+    } catch (...) {
+        if (job.valid()) job.wait();
+        throw;
+    }
+    if (job.valid()) job.get();
+}
+
 // resize(n) / a sized constructor of a vector with this allocator leave the new elements' memory as it is — for
 // arrays of plain data that the next loop fills on several threads (the first touch of the pages included), where
 // value-initialising them first would be one more pass, on one thread.  Every element must be assigned before it is read.
@@ -73,8 +108,20 @@ void parallel_chunks(size_t n, size_t min_chunk, size_t max_tasks, F&& fn) {
     const size_t tasks = std::max<size_t>(1, std::min(max_tasks, n / std::max<size_t>(min_chunk, 1)));
     if (tasks == 1) return fn((size_t)0, n);
     std::vector<std::future<void>> jobs;
-    for (size_t t = 1; t < tasks; ++t) jobs.push_back(run_async([&fn, n, t, tasks]() { fn(n * t / tasks, n * (t + 1) / tasks); }));
-    fn((size_t)0, n / tasks);
+    std::vector<size_t> here{0};  // the chunks that run on this thread: the first, and any whose thread did not start
+    for (size_t t = 1; t < tasks; ++t) {
+        try {
+            jobs.push_back(run_async([&fn, n, t, tasks]() { fn(n * t / tasks, n * (t + 1) / tasks); }));
+        } catch (const std::system_error&) {
+            here.push_back(t);
+        }
+    }
+    try {
+        for (size_t t : here) fn(n * t / tasks, n * (t + 1) / tasks);
+    } catch (...) {
+        for (auto& j : jobs) j.wait();
+        throw;
+    }
     for (auto& j : jobs) j.get();
 }
 
@@ -122,5 +169,7 @@ void run_team(size_t members, F&& fn) {
     fn((size_t)0, team);
     for (auto& j : jobs) j.get();
 }
+// (a team is all or nothing: when a member's thread cannot be started, run_team throws std::system_error before any
+// member has run, and the caller does the work on its own)
 
 }  // namespace rt
