@@ -790,6 +790,7 @@ int rt_load_scene(const char* yaml_path, double aspect_ratio, int use_bvh, rt_sc
     if (!yaml_path || !out) return set_error("rt_load_scene: null argument");
     try {
         auto hs = std::make_unique<HostScene>();
+        set_workers_disabled(BuildKnobs::from_environment().one_thread);
         load_scene_file(yaml_path, aspect_ratio, use_bvh != 0, *hs);
         if (use_bvh == 2) hs->desc.use_bvh = 2;
         *out = &hs.release()->desc;
@@ -825,6 +826,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         // Every knob of scene creation comes from the environment HERE, on the calling thread, before the first
         // worker starts: the workers read no environment (host/worker.h).
         const BuildKnobs knobs = BuildKnobs::from_environment();
+        set_workers_disabled(knobs.one_thread);
         // The device context (0.1-0.2 s in a cold process: HIP runtime, code objects) is created on the calling
         // thread, by the first HIP call below, and never beside this library's workers (with the runtime
         // initialising on a short-lived thread while the builds started and joined some thirty threads, one cold
@@ -843,7 +845,24 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
                 DeviceGuard first_use(build_device);
                 HIP_CHECK(hipFree(nullptr));
             }
-            auto render_job = run_async([&, build_device]() {
+            // beside this thread's work, or — with RT_BUILD_THREADS=1, or no thread to be had — right here, before it
+            auto start = [&](auto&& fn) -> std::future<void> {
+                if (!knobs.one_thread) {
+                    try {
+                        return run_async(fn);
+                    } catch (const std::system_error&) {
+                    }
+                }
+                std::promise<void> p;
+                try {
+                    fn();
+                    p.set_value();
+                } catch (...) {
+                    p.set_exception(std::current_exception());
+                }
+                return p.get_future();
+            };
+            auto render_job = start([&, build_device]() {
                 const auto r0 = std::chrono::steady_clock::now();
                 build_render_tree(*desc, *s, build_device, knobs);
                 s->info.render_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
@@ -854,7 +873,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
             render_job.get();
             const auto t2 = std::chrono::steady_clock::now();
             // beside the render flattening: the copy of what the f64 parity arrays will be made of, if ever asked for
-            auto source64 = run_async([&]() { capture_reference64_source(*desc, *s); });
+            auto source64 = start([&]() { capture_reference64_source(*desc, *s); });
             flatten_render(*desc, *s);
             const auto t3 = std::chrono::steady_clock::now();
             source64.get();

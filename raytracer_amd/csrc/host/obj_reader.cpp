@@ -265,7 +265,7 @@ void load_obj_first_model(const std::string& path, ObjMesh& out) {
                 runs.push_back(std::make_unique<Run>());
                 Run* run = runs.back().get();
                 const char* text = source.text.data();
-                if (last) return parse_block(text, begin, end, *run);  // nothing left to overlap it with
+                if (last || workers_disabled()) return parse_block(text, begin, end, *run);  // nothing left to overlap it with
                 if (jobs.size() - joined >= kInFlight) jobs[joined++].get();
                 try {
                     jobs.push_back(run_async([text, begin, end, run]() { parse_block(text, begin, end, *run); }));

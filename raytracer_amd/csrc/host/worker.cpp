@@ -18,14 +18,21 @@ BuildKnobs BuildKnobs::from_environment() {
     if (const char* v = getenv("RT_BUILD")) k.device_build = std::string(v) == "device";
     k.debug = getenv("RT_BUILD_DEBUG") != nullptr;
     if (const char* v = getenv("RT_BUILD_SMALL")) k.small = atoi(v);
+    if (const char* v = getenv("RT_BUILD_THREADS")) k.one_thread = atoi(v) == 1;
     return k;
 }
 
 namespace {
 std::atomic<int> g_forked_tasks{0};
+std::atomic<bool> g_workers_disabled{false};
 }  // namespace
 
-ForkSlot::ForkSlot() : taken(g_forked_tasks.fetch_add(1, std::memory_order_acq_rel) < kMaxForkedTasks) {
+void set_workers_disabled(bool off) { g_workers_disabled.store(off, std::memory_order_release); }
+bool workers_disabled() { return g_workers_disabled.load(std::memory_order_acquire); }
+
+ForkSlot::ForkSlot() : taken(false) {
+    if (workers_disabled()) return;
+    taken = g_forked_tasks.fetch_add(1, std::memory_order_acq_rel) < kMaxForkedTasks;
     if (!taken) g_forked_tasks.fetch_sub(1, std::memory_order_acq_rel);
 }
 ForkSlot::~ForkSlot() {

@@ -28,10 +28,15 @@ struct BuildKnobs {
     bool device_build = false;     // RT_BUILD=device
     bool debug = false;            // RT_BUILD_DEBUG: phase times on stderr
     int small = 0;                 // RT_BUILD_SMALL: device build, small-node threshold, 0 = default
+    bool one_thread = false;       // RT_BUILD_THREADS=1: scene creation on the calling thread alone (same trees: a test holds them to it)
     static BuildKnobs from_environment();
 };
 
 bool segv_trace_enabled();  // RT_SEGV_TRACE was set when the library was loaded
+// No worker threads for the work that follows (BuildKnobs::one_thread; process-wide, set by rt_scene_create for the
+// length of the call): forks are not made, teams have one member, chunked loops one chunk.
+void set_workers_disabled(bool off);
+bool workers_disabled();
 // this thread's alternate signal stack for as long as the object lives (nothing unless segv_trace_enabled())
 struct AltSignalStack {
     void* mem = nullptr;
@@ -105,7 +110,7 @@ struct Uninit : std::allocator<T> {
 // elements.  Small ranges stay on the calling thread.
 template <class F>
 void parallel_chunks(size_t n, size_t min_chunk, size_t max_tasks, F&& fn) {
-    const size_t tasks = std::max<size_t>(1, std::min(max_tasks, n / std::max<size_t>(min_chunk, 1)));
+    const size_t tasks = workers_disabled() ? 1 : std::max<size_t>(1, std::min(max_tasks, n / std::max<size_t>(min_chunk, 1)));
     if (tasks == 1) return fn((size_t)0, n);
     std::vector<std::future<void>> jobs;
     std::vector<size_t> here{0};  // the chunks that run on this thread: the first, and any whose thread did not start
@@ -149,7 +154,7 @@ struct Team {
 };
 template <class F>
 void run_team(size_t members, F&& fn) {
-    Team team(std::max<size_t>(members, 1));
+    Team team(workers_disabled() ? 1 : std::max<size_t>(members, 1));
     // the members start their work together or not at all: one that could not be started would be waited for at
     // the first barrier for ever
     std::atomic<int> go{-1};  // -1: wait, 0: leave, 1: run

@@ -49,6 +49,34 @@ def test_device_built_tree_finds_the_same_hits(ra, name):
     host.close(), dev.close()
 
 
+@pytest.mark.parametrize("name", ["lucy", "cornell_lucy", "dual"])
+def test_host_built_trees_do_not_depend_on_the_build_threads(ra, name, monkeypatch):
+    """Scene set-up runs on many threads (OBJ blocks parsed beside the inflater, forked subtrees attached as pieces,
+    the root's sort and partition on a team) and says the result is the one a single thread produces:
+    RT_BUILD_THREADS=1 does all of it on the calling thread, and the two scenes must be the same to the bit — the
+    figures of both trees, the reference tree's leaf order, the first hits of both kernels' arithmetic, and a
+    one-sample-per-pixel frame (one path per pixel: no summation order to differ by)."""
+    w, h = 320, 180
+    many = ra.Scene(ra.load_scene(scene_path(name), w / h), 0)
+    monkeypatch.setenv("RT_BUILD_THREADS", "1")
+    one = ra.Scene(ra.load_scene(scene_path(name), w / h), 0)
+    monkeypatch.delenv("RT_BUILD_THREADS")
+    mi, oi = many.info(), one.info()
+    for field in ("n_surfaces", "n_nodes", "n_leaves", "max_depth", "max_leaf_size", "render_nodes", "render_depth",
+                  "render_max_leaf", "n_loose"):
+        assert getattr(mi, field) == getattr(oi, field), field
+    assert np.array_equal(many.leaf_order(), one.leaf_order())
+    for precision in (32, 64):
+        a, b = many.primary_hits(w, h, precision=precision), one.primary_hits(w, h, precision=precision)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), precision
+    img_m, st_m = many.render(w, h, 1, collect_stats=True)
+    img_o, st_o = one.render(w, h, 1, collect_stats=True)
+    assert np.array_equal(img_m, img_o)
+    # the same tree is walked the same way: not one node visit or triangle test more
+    assert (st_m.node_visits, st_m.tri_tests) == (st_o.node_visits, st_o.tri_tests)
+    many.close(), one.close()
+
+
 TREE_SCENES = ["cornell", "cornell_lucy", "teapot", "lucy", "dual"]  # the golden scenes that have a render tree
 
 

@@ -261,6 +261,23 @@ def test_obj_bare_group_line_ends_the_first_model(ra, tmp_path):
         assert np.abs(d.triangles["v"]).max() <= 0.5  # re-centred on the first model's own box, not the merged one
 
 
+def test_reference_tree_does_not_depend_on_the_build_threads(ra, monkeypatch):
+    """The threaded set-up (forked subtrees attached as pieces, team sort at the root, OBJ blocks) against the same
+    work on the calling thread alone (RT_BUILD_THREADS=1): same triangles, same reference-topology tree."""
+    path = scene_path("lucy")
+    many_desc = ra.load_scene(path, 1.5)
+    many = ra.Scene(many_desc, ra.RT_DEVICE_NONE)
+    monkeypatch.setenv("RT_BUILD_THREADS", "1")
+    one_desc = ra.load_scene(path, 1.5)
+    one = ra.Scene(one_desc, ra.RT_DEVICE_NONE)
+    assert np.array_equal(many_desc.triangles["v"], one_desc.triangles["v"])
+    assert np.array_equal(many_desc.triangles["n"], one_desc.triangles["n"])
+    mi, oi = many.info(), one.info()
+    for field in ("n_nodes", "n_leaves", "max_depth", "max_leaf_size", "render_nodes", "render_depth", "render_max_leaf"):
+        assert getattr(mi, field) == getattr(oi, field), field
+    assert np.array_equal(many.leaf_order(), one.leaf_order())
+
+
 def test_host_only_scene_refuses_to_render(ra):
     s = ra.Scene(ra.load_scene(scene_path("quads"), 1.5), ra.RT_DEVICE_NONE)
     with pytest.raises(ra.api.RtError, match="host-only"):
