@@ -1,0 +1,152 @@
+"""Differential run of the HIP path against the oracle over random scene files (the generators of tests/synth.py
+with random counts, seeds, cameras — thin lens included — and frame sizes, odd ones among them).  Per scene:
+  * first hits of the f64 parity kernel: ids and t equal to the oracle's, bit for bit;
+  * first hits of the render kernels' f32 arithmetic: the swap / flip / dt budget of tests/test_gpu_edge.py;
+  * images of the three kernel organisations, both samplers, same seeds, 1 to 16 spp: the pixels whose paths parted
+    ways between f32 and f64 are counted against the frame's paths, the others must agree to rounding, the mean
+    luminance as a whole (bars below; tests/test_gpu_parity.py's RMSE bar is for 16 spp and more).
+Prints one line per scene and a summary; exit status 1 if any bar is missed.  The oracle is the checker here, as in
+tests/; nothing of it is on the product's path.
+usage (GPU box): python tools/fuzz_parity.py [--scenes N] [--seed S]"""
+import argparse, os, pathlib, re, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402,F401  (maps the HIP runtime first: raytracer_amd/api.py)
+import raytracer_amd as ra  # noqa: E402
+from oracle import ref  # noqa: E402
+import synth  # noqa: E402
+from test_gpu_parity import classify_f32  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scenes", type=int, default=60)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--only", type=int, default=-1, help="compare this scene of the sequence only (the others are drawn and skipped)")
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+ref.lib()
+
+
+def random_camera(text):
+    """The generator's fixed camera replaced by a random one looking at the scene's middle, one in three with a lens."""
+    frm = [rng.uniform(-5, 5), rng.uniform(0.6, 4.5), rng.uniform(5, 9.5)]
+    to = [rng.uniform(-1, 1), rng.uniform(0.2, 1.0), rng.uniform(-1, 1)]
+    cam = f"camera:\n  fov: {rng.uniform(25, 70):.2f}\n  from: [{frm[0]:.3f}, {frm[1]:.3f}, {frm[2]:.3f}]\n  towards: [{to[0]:.3f}, {to[1]:.3f}, {to[2]:.3f}]\n"
+    if rng.integers(3) == 0:
+        cam += f"  aperture: {rng.uniform(0.02, 0.4):.3f}\n  focus_distance: {rng.uniform(4, 11):.3f}\n"
+    return re.sub(r"^camera:\n(?:  .*\n)+", cam, text, count=1, flags=re.M)
+
+
+def make_scene(tmp, k):
+    kind = ["many_prims", "many_prims_no_mesh", "spheres_only", "room", "many_quads", "few_loose"][k % 6]
+    seed = int(rng.integers(1 << 30))
+    if kind == "many_prims":
+        path = synth.many_prims(tmp, n_spheres=int(rng.integers(12, 60)), n_quads=int(rng.integers(1, 12)), seed=seed)
+    elif kind == "many_prims_no_mesh":
+        path = synth.many_prims(tmp, n_spheres=int(rng.integers(28, 70)), n_quads=int(rng.integers(3, 10)), with_mesh=False, seed=seed)
+    elif kind == "spheres_only":
+        path = synth.many_prims(tmp, n_spheres=int(rng.integers(34, 90)), n_quads=0, with_mesh=False, seed=seed)
+    elif kind == "room":
+        path = synth.room(tmp, n_spheres=int(rng.integers(4, 40)), seed=seed)
+    elif kind == "many_quads":
+        path = synth.many_quads(tmp, n=int(rng.integers(31, 90)), seed=seed)
+    else:  # everything loose: no render tree at all, or loose primitives beside a small mesh
+        path = synth.many_prims(tmp, n_spheres=int(rng.integers(1, 9)), n_quads=int(rng.integers(1, 5)), with_mesh=bool(rng.integers(2)), seed=seed)
+    text = open(path).read()
+    if kind != "room":  # (the room's camera has to stay inside it)
+        text = random_camera(text)
+    open(path, "w").write(text)
+    return kind, seed, path
+
+
+# Largest relative dt of an f32 first hit on the same surface.  tests/ hold the shipped scenes to 2e-4; a random camera
+# finds the radius-100 ground at its horizon, where the ray's f32 direction (the render kernels' representation) moves
+# a grazing root by more: 2.9e-4 at the worst pixel of 2000 scenes (seed 7, scene 1878, pixel (33, 5)).
+F32_DT_MAX = 1e-3
+SAME_PATH = 2e-3        # largest difference of a pixel whose paths agree (radiance, averaged over the pixel's samples)
+SAME_PATH_RMSE = 2e-4   # per-channel RMSE over those pixels
+PARTED_FRACTION = 2e-3  # paths of a frame that may part ways (plus three)
+LUM_BAR = 5e-3          # relative mean luminance of the whole frame, moved pixels included (frames of a few thousand paths)
+bad = 0
+parted_total = paths_total = caught_total = 0
+worst = {"rmse": 0.0, "lum": 0.0, "swaps": 0, "flips": 0, "rel": 0.0, "parted": 0.0}
+t_start = time.time()
+for k in range(args.scenes):
+    with tempfile.TemporaryDirectory() as d:
+        kind, seed, path = make_scene(pathlib.Path(d), k)
+        w, h = int(rng.integers(40, 200)), int(rng.integers(30, 130))
+        sn = int(rng.integers(1, 5))
+        if args.only >= 0 and k != args.only:
+            continue
+        scene = ra.Scene(ra.load_scene(path, w / h), 0)
+        oracle = ref.RefScene.from_yaml(path, w / h)
+        notes = []
+        rid, rt = oracle.primary_hits(w, h, threads=16)
+        ids, t = scene.primary_hits(w, h, precision=64)
+        if not (np.array_equal(ids, rid) and np.array_equal(t, rt)):
+            notes.append(f"f64 first hits differ: {int((ids != rid).sum())} ids, {int((t != rt).sum())} t")
+        ids32, t32 = scene.primary_hits(w, h, precision=32)
+        # The f32 triangle test takes hits within 2^-20 of an edge (device_rt.h: no ray slips between two triangles of a
+        # mesh); the reference's test, and so the oracle's, loses a ray that runs exactly along a shared edge — the
+        # jitter-free probe's centre column lies in the plane x = 0 exactly, and so does an edge of tests/synth.py's
+        # room mesh.  Such pixels (f32: a triangle, nearer than what f64 finds behind the crack) are counted apart.
+        desc = ra.load_scene(path, w / h)
+        is_tri = np.concatenate([desc.surfaces["type"] == 1, [False]])  # (id -1: no hit)
+        behind = np.where(rid >= 0, rt, np.inf)
+        caught = (ids32 != rid) & is_tri[ids32] & (t32 < behind * (1.0 - 1e-5))  # (nearer by more than a tie's rounding)
+        caught_total += int(caught.sum())
+        ids32 = np.where(caught, rid, ids32)
+        t32 = np.where(caught, rt, t32)
+        swaps, flips, n_rel, max_rel = classify_f32(ids32, t32, rid, rt)
+        if flips > max(4, 1e-3 * rid.size) or swaps > max(8, 5e-3 * rid.size) or n_rel > 4 or max_rel > F32_DT_MAX:
+            notes.append(f"f32 first hits: swaps {swaps} flips {flips} n_rel {n_rel} max_rel {max_rel:.2e}")
+            diff = np.argwhere(ids32 != rid)
+            notes.append("ids differ at " + ", ".join(f"({i}, {j}): f32 {int(ids32[j, i])} t {t32[j, i]:.7g} / f64 {int(rid[j, i])} t {rt[j, i]:.7g}" for j, i in diff[:10]))
+            same = (ids32 == rid) & (rid >= 0)
+            rel = np.where(same, np.abs(t32 - rt) / np.where(rt > 0, rt, 1), 0)
+            j, i = np.unravel_index(np.argmax(rel), rel.shape)
+            sref = desc.surfaces[int(rid[j, i])]
+            notes.append(f"worst dt at pixel ({i}, {j}): surface {int(rid[j, i])} type {int(sref['type'])} index {int(sref['index'])}, "
+                         f"t64 {rt[j, i]:.9g} t32 {t32[j, i]:.9g}"
+                         + (f", triangle {desc.triangles[int(sref['index'])]['v'].tolist()}" if int(sref['type']) == 1 else ""))
+        worst["swaps"], worst["flips"], worst["rel"] = max(worst["swaps"], swaps), max(worst["flips"], flips), max(worst["rel"], max_rel)
+        n = sn * sn
+        for sampler in (0, 1):
+            want, _ = oracle.render(w, h, sn, threads=16, sampler=sampler)
+            want = want / n
+            for kernel in (0, 1, 2):
+                img, st = scene.render(w, h, sn, kernel=kernel, sampler=sampler, collect_stats=True)
+                got = img.astype(np.float64) / n
+                if not np.isfinite(got).all() or st.samples != w * h * n:
+                    notes.append(f"kernel {kernel} sampler {sampler}: non-finite radiance or {st.samples} samples")
+                    continue
+                # A pixel whose paths are the same on both sides differs by rounding only (f32 sums against f64: below
+                # SAME_PATH); one path that parts ways — a rounding-sensitive decision somewhere along it, more often the
+                # more curved mirrors it has met — moves its pixel by up to its throughput / n, or by a light's
+                # radiance.  So: the pixels that moved are counted against the frame's paths, the rest must agree
+                # closely, and the mean luminance must agree whatever moved.
+                dev = np.abs(got - want).max(axis=-1)
+                parted = dev > SAME_PATH
+                keep = ~parted
+                rmse = float(np.sqrt(np.mean((got[keep] - want[keep]) ** 2, axis=0)).max()) if keep.any() else 0.0
+                lum = abs(got.mean() - want.mean()) / max(want.mean(), 1e-6)
+                frac = parted.sum() / (w * h * n)
+                worst["rmse"], worst["lum"] = max(worst["rmse"], rmse), max(worst["lum"], lum)
+                worst["parted"] = max(worst["parted"], frac)
+                parted_total += int(parted.sum())
+                paths_total += w * h * n
+                if parted.sum() > 3 + PARTED_FRACTION * w * h * n or rmse > SAME_PATH_RMSE or lum > LUM_BAR:
+                    notes.append(f"kernel {kernel} sampler {sampler}: {int(parted.sum())} pixels moved ({frac:.1e} of the paths), "
+                                 f"rmse of the rest {rmse:.1e}, luminance {lum:.1e}")
+        info = scene.info()
+        scene.close()
+        bad += bool(notes)
+        print(f"{k:3d} {kind:18s} seed {seed:10d} {w:3d}x{h:<3d} sn {sn} surfaces {info.n_surfaces:4d} loose {info.n_loose:2d} "
+              f"render nodes {info.render_nodes:4d}: {'ok' if not notes else '; '.join(notes)}", flush=True)
+print(f"{args.scenes} scenes in {time.time() - t_start:.0f} s, {bad} with a missed bar.  Images: {parted_total} of {paths_total} paths "
+      f"parted ways ({parted_total / max(paths_total, 1):.1e}; worst frame {worst['parted']:.1e}, bar {PARTED_FRACTION} + 3), rmse of the pixels that did "
+      f"not move at most {worst['rmse']:.1e} (bar {SAME_PATH_RMSE}), mean luminance within {worst['lum']:.1e} (bar {LUM_BAR}).  f32 first hits: "
+      f"at most {worst['swaps']} tie-swaps and {worst['flips']} flips a frame, max rel dt {worst['rel']:.2e}; {caught_total} pixels where "
+      f"the f32 test held a ray on a shared triangle edge that the f64 test lets through")
+sys.exit(1 if bad else 0)
