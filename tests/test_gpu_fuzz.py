@@ -1,6 +1,7 @@
 """A short session of tools/fuzz_parity.py under pytest: random scene files (tests/synth.py's generators with random
 counts, seeds, cameras and frame sizes) through the C ABI against the oracle — f64 first hits bit for bit, f32 first
-hits within their budget, six frames per scene.  The long sessions (2 x 3000 scenes) are in
+hits within their budget, six frames per scene; once over scene files, once over the example generators.  The long
+sessions (3 x 3000 scenes) are in
 profiles/r3_fuzz_parity.txt.  Needs an MI355X:  pytest -m gpu."""
 import os
 import subprocess
@@ -13,8 +14,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_random_scenes_against_the_oracle():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--scenes", "96", "--seed", "11"],
+@pytest.mark.parametrize("mode", [[], ["--examples"]], ids=["scene files", "example generators"])
+def test_random_scenes_against_the_oracle(mode):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--scenes", "96", "--seed", "11"] + mode,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "96 scenes" in out.stdout and "0 with a missed bar" in out.stdout
