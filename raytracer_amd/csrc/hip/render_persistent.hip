@@ -636,8 +636,17 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // teapot.yaml 6450 / 6605, dual.yaml 6605 / 6815 Msamples/s; lucy.yaml 13580 / 13500, cornell_lucy.yaml 4401 / 4396).
     const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K")))
                                                      : (sc.has_tree ? (tree_depth <= 18u ? 8u : 4u) : 1u);
-    // frames of 512 strata and more start with chunks twice as large (+1 %: fewer flushes, longer stays on a tile)
-    const uint32_t first_chunk = plan.my_strata >= 512u ? 2u * kChunkStrata : kChunkStrata;
+    // Frames of 512 strata and more start with chunks twice as large (+1 %: fewer flushes, longer stays on a tile).
+    // The large meshes (trees deeper than 18 levels) take larger ones still, and take them for the strata slices of
+    // several GPUs too — 64 strata from 256 on, 32 from 128 (tools/overlap_probe.py with RT_FIRST_CHUNK, awaited /
+    // three in flight, ms: lucy.yaml whole frame 140.6 / 139.8 -> 139.2 / 139.1, 1/2 72.0 -> 70.9, 1/4 38.0 / 37.5 ->
+    // 37.2 / 36.3, 1/8 20.7 / 19.9 -> 20.2 / 19.5; cornell_lucy.yaml +0.1...0.3 % throughout).  Not the small trees:
+    // dual.yaml's 1/8 slice at 32 takes 55 ms awaited instead of 40 (a heavy chunk late in the frame), 1/4 at 64: 107 for 76.
+    const bool large_mesh = sc.has_tree && tree_depth > 18u;
+    const uint32_t first_chunk =
+        getenv("RT_FIRST_CHUNK") ? (uint32_t)std::max(2, atoi(getenv("RT_FIRST_CHUNK")))
+        : large_mesh             ? (plan.my_strata >= 256u ? 4u * kChunkStrata : (plan.my_strata >= 128u ? 2u * kChunkStrata : kChunkStrata))
+                                 : (plan.my_strata >= 512u ? 2u * kChunkStrata : kChunkStrata);
     uint32_t done = 0, groups = 0;
     for (int p = 0; p < kPhases; ++p) {
         const uint32_t per = std::max(2u, first_chunk >> p), left = plan.my_strata - done;
