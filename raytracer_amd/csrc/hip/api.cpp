@@ -132,9 +132,9 @@ struct rt_scene {
     // The exact-parity kernel's f64 arrays (the un-rounded reference-topology tree) are parity-only data: flattened
     // and uploaded at the first rt_primary_hits(precision = 64), not at scene creation.  Until then the scene keeps
     // what that flattening reads beside the tree itself — the caller's rt_scene_desc need not outlive the call:
-    struct Reference64Source {
-        std::vector<rt_surface_ref> surfaces;
-        std::vector<double> tri_v;  // 9 per triangle
+    struct Reference64Source {  // (made on a worker thread, kept with the scene: OsBlocks, host/worker.h)
+        std::vector<rt_surface_ref, OsBlocks<rt_surface_ref>> surfaces;
+        std::vector<double, OsBlocks<double>> tri_v;  // 9 per triangle
         std::vector<rt_sphere> spheres;
         std::vector<rt_quad> quads;
     };
@@ -447,7 +447,7 @@ void build_render_tree(const rt_scene_desc& d, rt_scene& s, int build_device, co
         build_render_bvh(d, tree_ids, max_leaf, knobs.traversal_cost, rb);
     } else {  // --no-bvh: one leaf, every surface tested by every ray (main.rs:60-65)
         rb = Bvh{};
-        rb.order = tree_ids;
+        rb.order.assign(tree_ids.begin(), tree_ids.end());
         if (!tree_ids.empty()) {
             BvhNode leaf;
             leaf.box = Aabb::empty();

@@ -228,7 +228,7 @@ struct Builder {
         int32_t l, r;
         Aabb lbox, rbox;
         if (depth <= kParallelDepth && split >= kParallelMin && n - split >= kParallelMin) {
-            auto left_tree = std::make_unique<TreePiece>(), right_tree = std::make_unique<TreePiece>();
+            auto left_tree = std::make_unique<TreePiece>(split), right_tree = std::make_unique<TreePiece>(n - split);
             fork_join(
                 [&]() {
                     Builder b(items, left_tree.get());
@@ -482,7 +482,7 @@ void build_bvh(const rt_scene_desc& d, Bvh& out) {
     parallel_chunks(d.n_surfaces, 8192, 8, [&](size_t begin, size_t end) {
         for (size_t i = begin; i < end; ++i) items[i] = {surface_bounds(d, d.surfaces[i]), (int32_t)i};
     });
-    TreePiece piece;
+    TreePiece piece(d.n_surfaces);
     Builder b(items, &piece);
     Aabb box;
     if (d.use_bvh)

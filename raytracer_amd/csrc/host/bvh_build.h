@@ -25,8 +25,9 @@ struct BvhNode {
 };
 
 struct Bvh {
-    std::vector<BvhNode> nodes;   // nodes[0] is the root
-    std::vector<int32_t> order;   // surface ids, in-order over the leaves
+    // (OsBlocks: the render tree's arrays are made on a worker thread and live as long as the scene — see worker.h)
+    std::vector<BvhNode, OsBlocks<BvhNode>> nodes;  // nodes[0] is the root
+    std::vector<int32_t, OsBlocks<int32_t>> order;  // surface ids, in-order over the leaves
     uint32_t max_depth = 0;       // root = 1
     uint32_t max_leaf_size = 0;
     uint32_t n_leaves = 0;
@@ -44,8 +45,8 @@ struct Bvh {
 // from the piece's first node.  (The pieces used to be copied into their parent at every join: a node of lucy's
 // tree was copied four times, the last copies on one thread while the others had ended — 6 of the render tree's 19 ms.)
 struct TreePiece {
-    std::vector<BvhNode> own;  // the nodes this task made, in the order it made them
-    std::vector<int32_t> pos;  // own[i]'s index in the piece
+    std::vector<BvhNode, OsBlocks<BvhNode>> own;  // the nodes this task made, in the order it made them
+    std::vector<int32_t, OsBlocks<int32_t>> pos;  // own[i]'s index in the piece
     struct Attached {
         int32_t at;
         std::unique_ptr<TreePiece> piece;
@@ -53,6 +54,9 @@ struct TreePiece {
     std::vector<Attached> attached;
     int32_t size = 0;  // nodes of the piece, attached pieces included
     uint32_t max_depth = 0, max_leaf_size = 0, n_leaves = 0;
+    TreePiece() = default;
+    // a piece over n_items items: at most 2 n - 1 nodes, room for which is taken once (address space; pages come as they are written)
+    explicit TreePiece(size_t n_items) { own.reserve(2 * n_items), pos.reserve(2 * n_items); }
 
     // the index of the new node; own.back() is the node (the caller keeps own.size() - 1 to come back to it)
     int32_t push(const BvhNode& n) {

@@ -151,13 +151,13 @@ bool parse_corner(const char* tok, size_t len, RawCorner& out) {
 // relative (negative) indices can be resolved once the blocks before it have been counted; line numbers count from
 // the block's first line.
 struct Run {
-    std::vector<float> pos, nrm;
+    std::vector<float, OsBlocks<float>> pos, nrm;
     struct Face {
         RawCorner c[3];
         size_t pos_before, nrm_before;  // v / vn lines of this block above the face
         size_t line;
     };
-    std::vector<Face> faces;
+    std::vector<Face, OsBlocks<Face>> faces;
     // every object / group statement of the block: the first one that follows a face — of this block or an earlier
     // one — ends the first model (only the first model is used, load.rs:225-229)
     struct Mark {

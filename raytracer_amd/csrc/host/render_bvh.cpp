@@ -63,7 +63,7 @@ struct RBuilder {
                   uint32_t depth) {
         int32_t l, r;
         if (depth <= kParallelDepth && mid - first >= kParallelMin && first + n - mid >= kParallelMin) {
-            auto left_tree = std::make_unique<TreePiece>(), right_tree = std::make_unique<TreePiece>();
+            auto left_tree = std::make_unique<TreePiece>(mid - first), right_tree = std::make_unique<TreePiece>(first + n - mid);
             fork_join(
                 [&]() {
                     RBuilder b(items, left_tree.get(), max_leaf, traversal_cost);
@@ -318,7 +318,7 @@ struct RBuilder {
 void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, uint32_t max_leaf, double traversal_cost, Bvh& out) {
     out = Bvh{};
     Items items(ids.size());  // (filled below, in runs, by the threads that then own the pages)
-    TreePiece piece;
+    TreePiece piece(ids.size());
     RBuilder b(items, &piece, std::max(1u, max_leaf), traversal_cost);
     // (the node array's pages are touched for the first time beside the build, not after it: at most 2n - 1 nodes)
     auto node_room = run_async([&]() { out.nodes.resize(2 * ids.size()); });

@@ -2,6 +2,7 @@
 
 #include <execinfo.h>
 #include <signal.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -26,6 +27,13 @@ namespace {
 std::atomic<int> g_forked_tasks{0};
 std::atomic<bool> g_workers_disabled{false};
 }  // namespace
+
+void* os_block(size_t bytes) {
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) throw std::bad_alloc();
+    return p;
+}
+void os_block_free(void* p, size_t bytes) noexcept { munmap(p, bytes); }
 
 void set_workers_disabled(bool off) { g_workers_disabled.store(off, std::memory_order_release); }
 bool workers_disabled() { return g_workers_disabled.load(std::memory_order_acquire); }

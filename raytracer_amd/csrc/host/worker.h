@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <future>
 #include <memory>
+#include <new>
 #include <system_error>
 #include <thread>
 #include <utility>
@@ -88,16 +89,51 @@ void fork_join(Child&& child, Rest&& rest) {
     if (job.valid()) job.get();
 }
 
-// resize(n) / a sized constructor of a vector with this allocator leave the new elements' memory as it is — for
-// arrays of plain data that the next loop fills on several threads (the first touch of the pages included), where
-// value-initialising them first would be one more pass, on one thread.  Every element must be assigned before it is read.
+// Memory for the workers' arrays and for what they leave with the scene.  Blocks of kOsBlockBytes and more come
+// straight from the operating system and go straight back (mmap / munmap): a worker thread's malloc arena keeps
+// what is freed in it — glibc trims a thread arena only past a threshold that rises with every large block freed,
+// 64 MB in the end — and with the render tree's node array (14 MB on lucy.yaml), the copy the f64 parity arrays
+// are made from (9 MB) and a tree piece or a sort's scratch of a few MB each made on some forty short-lived
+// threads, a process that loaded scene after scene held 500 MB of such memory at rest (110 arena heaps of
+// 17-23 MB; RSS 430 -> 690 MB over 300 loads of the shipped scenes, 100-170 MB with MALLOC_ARENA_MAX=2).
+// With the blocks of 1 MB and more out of the arenas: 330 MB; of 384 KB and more: 210 MB, of 128 KB and more:
+// 105 MB — but fresh pages from the OS are zeroed pages, and a scene's creation takes 2 ms more (17.5 -> 19.5)
+// and 4 ms more: the threshold is where creation time does not move.  Smaller blocks are malloc's.
+constexpr size_t kOsBlockBytes = 1 << 20;
+void* os_block(size_t bytes);            // throws std::bad_alloc
+void os_block_free(void* p, size_t bytes) noexcept;
 template <class T>
-struct Uninit : std::allocator<T> {
+struct OsBlocks {
+    using value_type = T;
+    OsBlocks() = default;
+    template <class U>
+    OsBlocks(const OsBlocks<U>&) noexcept {}
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        return static_cast<T*>(bytes >= kOsBlockBytes ? os_block(bytes) : ::operator new(bytes));
+    }
+    void deallocate(T* p, size_t n) noexcept {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= kOsBlockBytes) os_block_free(p, bytes);
+        else ::operator delete(p);
+    }
+    template <class U>
+    bool operator==(const OsBlocks<U>&) const noexcept { return true; }
+    template <class U>
+    bool operator!=(const OsBlocks<U>&) const noexcept { return false; }
+};
+// The same, and resize(n) / a sized constructor leave the new elements' memory as it is — for arrays of plain data
+// that the next loop fills on several threads (the first touch of the pages included), where value-initialising
+// them first would be one more pass, on one thread.  Every element must be assigned before it is read.
+template <class T>
+struct Uninit : OsBlocks<T> {
     template <class U>
     struct rebind {
         using other = Uninit<U>;
     };
-    using std::allocator<T>::allocator;
+    Uninit() = default;
+    template <class U>
+    Uninit(const Uninit<U>&) noexcept {}
     template <class U>
     void construct(U*) noexcept {}
     template <class U, class... A>
