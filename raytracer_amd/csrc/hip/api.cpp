@@ -845,24 +845,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
                 DeviceGuard first_use(build_device);
                 HIP_CHECK(hipFree(nullptr));
             }
-            // beside this thread's work, or — with RT_BUILD_THREADS=1, or no thread to be had — right here, before it
-            auto start = [&](auto&& fn) -> std::future<void> {
-                if (!knobs.one_thread) {
-                    try {
-                        return run_async(fn);
-                    } catch (const std::system_error&) {
-                    }
-                }
-                std::promise<void> p;
-                try {
-                    fn();
-                    p.set_value();
-                } catch (...) {
-                    p.set_exception(std::current_exception());
-                }
-                return p.get_future();
-            };
-            auto render_job = start([&, build_device]() {
+            // (tasks of the pool, host/worker.h: beside this thread's work, or — with RT_BUILD_THREADS=1 — right here)
+            ScopedTask render_job([&, build_device]() {
                 const auto r0 = std::chrono::steady_clock::now();
                 build_render_tree(*desc, *s, build_device, knobs);
                 s->info.render_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
@@ -873,7 +857,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
             render_job.get();
             const auto t2 = std::chrono::steady_clock::now();
             // beside the render flattening: the copy of what the f64 parity arrays will be made of, if ever asked for
-            auto source64 = start([&]() { capture_reference64_source(*desc, *s); });
+            ScopedTask source64([&]() { capture_reference64_source(*desc, *s); });
             flatten_render(*desc, *s);
             const auto t3 = std::chrono::steady_clock::now();
             source64.get();

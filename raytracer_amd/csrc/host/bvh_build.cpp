@@ -10,10 +10,10 @@
 namespace rt {
 
 void TreePiece::lay_out(BvhNode* dst, int32_t base) const {
-    // the big attached pieces on threads of their own, the rest here
-    std::vector<std::future<void>> jobs;
+    // the big attached pieces as tasks of their own, the rest here
+    std::vector<TaskRef> jobs;
     for (const Attached& a : attached) {
-        if (a.piece->size >= 4096) jobs.push_back(run_async([&a, dst, base]() { a.piece->lay_out(dst, base + a.at); }));
+        if (a.piece->size >= 4096) jobs.push_back(pool_submit([&a, dst, base]() { a.piece->lay_out(dst, base + a.at); }));
         else a.piece->lay_out(dst, base + a.at);
     }
     for (size_t i = 0; i < own.size(); ++i) {
@@ -21,7 +21,7 @@ void TreePiece::lay_out(BvhNode* dst, int32_t base) const {
         if (!n.is_leaf()) n.left += base, n.right += base;
         dst[base + pos[i]] = n;
     }
-    for (auto& j : jobs) j.get();
+    for (auto& j : jobs) pool_wait(j);
 }
 
 void TreePiece::finish(Bvh& out) const {

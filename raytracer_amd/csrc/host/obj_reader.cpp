@@ -248,15 +248,15 @@ void parse_block(const char* text, size_t begin, size_t end, Run& out) {
 }  // namespace
 
 void load_obj_first_model(const std::string& path, ObjMesh& out) {
-    // The blocks of lines are parsed as they come out of the inflater, each on a thread of its own (strtof is most of
+    // The blocks of lines are parsed as they come out of the inflater, each as a task of the pool (strtof is most of
     // what is left of a large mesh's load time), at most kInFlight of them at a time.
     constexpr size_t kBlockBytes = 256 << 10, kInFlight = 16;
     BlockSource source;
     std::vector<std::unique_ptr<Run>> runs;
-    std::vector<std::future<void>> jobs;  // (futures, not bare threads: a failed thread start or a throwing parse unwinds through joins)
+    std::vector<TaskRef> jobs;
     size_t joined = 0;
     auto join_all = [&]() {
-        for (; joined < jobs.size(); ++joined) jobs[joined].get();
+        for (; joined < jobs.size(); ++joined) pool_wait(jobs[joined]);
     };
     try {
         source.run(
@@ -266,16 +266,17 @@ void load_obj_first_model(const std::string& path, ObjMesh& out) {
                 Run* run = runs.back().get();
                 const char* text = source.text.data();
                 if (last || workers_disabled()) return parse_block(text, begin, end, *run);  // nothing left to overlap it with
-                if (jobs.size() - joined >= kInFlight) jobs[joined++].get();
-                try {
-                    jobs.push_back(run_async([text, begin, end, run]() { parse_block(text, begin, end, *run); }));
-                } catch (const std::system_error&) {  // no thread to be had: parse it here
-                    parse_block(text, begin, end, *run);
-                }
+                if (jobs.size() - joined >= kInFlight) pool_wait(jobs[joined++]);
+                jobs.push_back(pool_submit([text, begin, end, run]() { parse_block(text, begin, end, *run); }));
             },
             join_all);
     } catch (...) {
-        for (; joined < jobs.size(); ++joined) jobs[joined].wait();  // no worker outlives the text it reads
+        for (; joined < jobs.size(); ++joined) {  // no task outlives the text it reads
+            try {
+                pool_wait(jobs[joined]);
+            } catch (...) {
+            }
+        }
         throw;
     }
     join_all();

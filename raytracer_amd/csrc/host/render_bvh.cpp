@@ -225,16 +225,11 @@ struct RBuilder {
                 // each with bins of its own, united afterwards (counts add up, boxes merge: the order does not matter)
                 const size_t parts = std::min<size_t>(8, n / (kParallelBinMin / 4));
                 std::vector<Bins> part(parts);
-                std::vector<std::future<void>> jobs;
-                for (size_t t = 1; t < parts; ++t) {
-                    try {
-                        jobs.push_back(run_async([&, t]() { bin_range(first + n * t / parts, first + n * (t + 1) / parts, part[t]); }));
-                    } catch (const std::system_error&) {  // no thread to be had: this run here
-                        bin_range(first + n * t / parts, first + n * (t + 1) / parts, part[t]);
-                    }
-                }
+                std::vector<TaskRef> jobs;
+                for (size_t t = 1; t < parts; ++t)
+                    jobs.push_back(pool_submit([&, t]() { bin_range(first + n * t / parts, first + n * (t + 1) / parts, part[t]); }));
                 bin_range(first, first + n / parts, part[0]);
-                for (auto& j : jobs) j.get();
+                for (auto& j : jobs) pool_wait(j);
                 for (const Bins& p : part)
                     for (int axis = 0; axis < 3; ++axis)
                         for (int k = 0; k < kBins; ++k)
@@ -321,7 +316,7 @@ void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, u
     TreePiece piece(ids.size());
     RBuilder b(items, &piece, std::max(1u, max_leaf), traversal_cost);
     // (the node array's pages are touched for the first time beside the build, not after it: at most 2n - 1 nodes)
-    auto node_room = run_async([&]() { out.nodes.resize(2 * ids.size()); });
+    ScopedTask node_room([&]() { out.nodes.resize(2 * ids.size()); });
     constexpr size_t kChunks = 8;
     RBuilder::Bounds part[kChunks];
     std::atomic<size_t> next_part{0};
@@ -338,12 +333,7 @@ void build_render_bvh(const rt_scene_desc& d, const std::vector<int32_t>& ids, u
     });
     RBuilder::Bounds all;
     for (const RBuilder::Bounds& p : part) all.box = all.box.merge(p.box), all.cb = all.cb.merge(p.cb);
-    try {
-        if (!ids.empty()) b.build(0, ids.size(), all, 1);
-    } catch (...) {
-        node_room.wait();
-        throw;
-    }
+    if (!ids.empty()) b.build(0, ids.size(), all, 1);
     node_room.get();
     piece.finish(out);
     out.order.resize(ids.size());

@@ -1,11 +1,16 @@
 #include "worker.h"
 
 #include <execinfo.h>
+#include <pthread.h>
 #include <signal.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -27,6 +32,125 @@ namespace {
 std::atomic<int> g_forked_tasks{0};
 std::atomic<bool> g_workers_disabled{false};
 }  // namespace
+
+// ---- the pool
+struct PoolTask {
+    std::function<void()> fn;
+    std::exception_ptr error;
+    std::atomic<int> state{0};  // 0 queued, 1 taken, 2 done
+};
+
+namespace {
+
+struct Pool {
+    std::mutex mutex;
+    std::condition_variable work, done;  // work: a task was queued (or the pool ends); done: a task finished
+    std::deque<TaskRef> queue;
+    bool started = false;
+
+    static void run(const TaskRef& t) {  // t->state is 1, set by the caller under the mutex
+        try {
+            t->fn();
+        } catch (...) {
+            t->error = std::current_exception();
+        }
+        t->fn = nullptr;
+    }
+    void finish(const TaskRef& t) {
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            t->state.store(2, std::memory_order_release);
+        }
+        done.notify_all();
+    }
+    void thread_main() {
+        AltSignalStack alt;
+        std::unique_lock<std::mutex> lock(mutex);
+        while (true) {
+            work.wait(lock, [this]() { return !queue.empty(); });
+            TaskRef t = std::move(queue.front());  // the oldest: the largest subtrees were forked first
+            queue.pop_front();
+            t->state.store(1, std::memory_order_relaxed);
+            lock.unlock();
+            run(t);
+            finish(t);
+            lock.lock();
+        }
+    }
+    void start_threads() {  // under the mutex
+        started = true;
+        const unsigned want = std::min(15u, std::max(2u, std::thread::hardware_concurrency()) - 1u);
+        for (unsigned i = 0; i < want; ++i) {
+            try {
+                std::thread([this]() { thread_main(); }).detach();
+            } catch (const std::system_error&) {  // as many as there are to be had
+                break;
+            }
+        }
+    }
+};
+// The pool lives until the process ends and its threads are never joined: they sleep between scenes and go with the
+// process.  (A destructor at exit would have to wake and join them — and in a child process made by fork() there is
+// nothing to join: only the forking thread exists there.  The child starts a pool of its own at its first task.)
+Pool* g_pool = nullptr;
+std::once_flag g_pool_once;
+Pool& pool() {
+    std::call_once(g_pool_once, []() {
+        g_pool = new Pool;
+        // fork(): taken with the pool at rest (its mutex held across the call); the child gets a pool of its own — the
+        // parent's is left as it was copied, mutex held, its condition variables knowing of sleepers that do not exist
+        pthread_atfork([]() { g_pool->mutex.lock(); }, []() { g_pool->mutex.unlock(); }, []() { g_pool = new Pool; });
+    });
+    return *g_pool;
+}
+
+}  // namespace
+
+TaskRef pool_submit(std::function<void()> f) {
+    TaskRef t = std::make_shared<PoolTask>();
+    t->fn = std::move(f);
+    if (workers_disabled()) {
+        t->state.store(1, std::memory_order_relaxed);
+        Pool::run(t);
+        t->state.store(2, std::memory_order_release);
+        return t;
+    }
+    Pool& p = pool();
+    {
+        std::lock_guard<std::mutex> lock(p.mutex);
+        if (!p.started) p.start_threads();
+        p.queue.push_back(t);
+    }
+    p.work.notify_one();
+    return t;
+}
+
+void pool_wait(const TaskRef& task) {
+    Pool& p = pool();
+    std::unique_lock<std::mutex> lock(p.mutex);
+    while (task->state.load(std::memory_order_acquire) != 2) {
+        TaskRef mine;
+        if (task->state.load(std::memory_order_relaxed) == 0) {  // nobody has taken it: it is this thread's
+            auto it = std::find(p.queue.begin(), p.queue.end(), task);
+            if (it != p.queue.end()) p.queue.erase(it);
+            mine = task;
+        } else if (!p.queue.empty()) {  // somebody is at it: help with the newest task meanwhile
+            mine = std::move(p.queue.back());
+            p.queue.pop_back();
+        }
+        if (mine) {
+            mine->state.store(1, std::memory_order_relaxed);
+            lock.unlock();
+            Pool::run(mine);
+            p.finish(mine);
+            lock.lock();
+        } else {
+            p.done.wait(lock);  // (woken by every task that finishes, and a newly queued one is found on the way round)
+        }
+    }
+    lock.unlock();
+    if (task->error) std::rethrow_exception(task->error);
+}
 
 void* os_block(size_t bytes) {
     void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);

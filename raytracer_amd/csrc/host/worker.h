@@ -5,14 +5,15 @@
 //    and the HIP runtime's initialisation does change it (libhsa-runtime64 and librocprofiler-register import
 //    setenv).  Every RT_* knob of scene creation is read once, by BuildKnobs::from_environment on the thread that
 //    calls rt_scene_create, before the first worker exists, and handed down by value;
-//  * a worker starts through run_async, which (with RT_SEGV_TRACE set) gives the thread an alternate signal stack
-//    before its work, so that a fault on it — a stack overflow included — prints its stack instead of ending the
-//    process silently.
+//  * a worker thread — the pool's, a team's — has (with RT_SEGV_TRACE set) an alternate signal stack before it does
+//    any work, so that a fault on it — a stack overflow included — prints its stack instead of ending the process
+//    silently.
 #pragma once
 #include <cstdint>
 #include <algorithm>
 #include <atomic>
 #include <cstddef>
+#include <functional>
 #include <future>
 #include <memory>
 #include <new>
@@ -47,6 +48,7 @@ struct AltSignalStack {
     AltSignalStack& operator=(const AltSignalStack&) = delete;
 };
 
+// A thread of its own for f, now: for the members of a team (run_team), which must run side by side.
 template <class F>
 auto run_async(F&& f) {
     return std::async(std::launch::async, [fn = std::forward<F>(f)]() mutable {
@@ -55,10 +57,42 @@ auto run_async(F&& f) {
     });
 }
 
-// How many forked tasks of the tree builds may be alive in this process at a time (both trees together).  A fork
-// beyond it — or one whose thread cannot be started — is simply not made: the parent builds that child itself, and
-// the tree is the same either way.  (Eight ranks on one node each build their scene; a process that started a
-// thread for every subtree of 2 048 items would hold a hundred of them against the node's task limit.)
+// Everything else the set-up does beside the calling thread — parser blocks, forked subtrees, chunked loops, the
+// render tree's build — is a task for the process's pool: up to 15 threads, started at the first task and kept (a
+// thread per task it was at first: some sixty thread starts per scene, and as many malloc arenas left behind).
+// submit() queues f — or runs it at once when workers are disabled; wait() returns when the task is done and
+// rethrows what it threw.  A waiter does not sleep while there is work: it runs its own task itself if no pool
+// thread has taken it yet, then other queued tasks — so a task may submit and wait for tasks of its own, nothing
+// ever waits for a free thread, and a pool without a single thread (none could be started; a forked child process)
+// only means that the waiters do the work.
+struct PoolTask;
+using TaskRef = std::shared_ptr<PoolTask>;
+TaskRef pool_submit(std::function<void()> f);
+void pool_wait(const TaskRef& task);
+// A submitted task that is waited for when the scope ends, whatever ends it (a task works on its submitter's locals);
+// get() waits now and rethrows what the task threw.
+struct ScopedTask {
+    TaskRef task;
+    explicit ScopedTask(std::function<void()> f) : task(pool_submit(std::move(f))) {}
+    ScopedTask(const ScopedTask&) = delete;
+    ScopedTask& operator=(const ScopedTask&) = delete;
+    void get() {
+        const TaskRef t = std::move(task);
+        task = nullptr;
+        if (t) pool_wait(t);
+    }
+    ~ScopedTask() {
+        if (!task) return;
+        try {
+            pool_wait(task);
+        } catch (...) {
+        }
+    }
+};
+
+// How many forked tasks of the tree builds may be queued or running in this process at a time (both trees
+// together).  A fork beyond it is simply not made: the parent builds that child itself, and the tree is the same
+// either way.
 constexpr int kMaxForkedTasks = 24;
 struct ForkSlot {
     bool taken;
@@ -67,26 +101,25 @@ struct ForkSlot {
     ForkSlot(const ForkSlot&) = delete;
     ForkSlot& operator=(const ForkSlot&) = delete;
 };
-// `child` on a thread of its own if a slot is free and the thread starts, else here and now; then `rest` here; both
-// done when it returns.
+// `child` as a task if a slot is free, else here and now; then `rest` here; both done when it returns.
 template <class Child, class Rest>
 void fork_join(Child&& child, Rest&& rest) {
     ForkSlot slot;
-    std::future<void> job;
-    if (slot.taken) {
-        try {
-            job = run_async([&child]() { child(); });
-        } catch (const std::system_error&) {  // no thread to be had: not an error, just no fork
-        }
-    }
-    if (!job.valid()) child();
+    TaskRef job;
+    if (slot.taken) job = pool_submit([&child]() { child(); });
+    else child();
     try {
         rest();
     } catch (...) {
-        if (job.valid()) job.wait();
+        if (job) {
+            try {
+                pool_wait(job);
+            } catch (...) {
+            }
+        }
         throw;
     }
-    if (job.valid()) job.get();
+    if (job) pool_wait(job);
 }
 
 // Memory for the workers' arrays and for what they leave with the scene.  Blocks of kOsBlockBytes and more come
@@ -148,22 +181,22 @@ template <class F>
 void parallel_chunks(size_t n, size_t min_chunk, size_t max_tasks, F&& fn) {
     const size_t tasks = workers_disabled() ? 1 : std::max<size_t>(1, std::min(max_tasks, n / std::max<size_t>(min_chunk, 1)));
     if (tasks == 1) return fn((size_t)0, n);
-    std::vector<std::future<void>> jobs;
-    std::vector<size_t> here{0};  // the chunks that run on this thread: the first, and any whose thread did not start
-    for (size_t t = 1; t < tasks; ++t) {
+    std::vector<TaskRef> jobs;
+    for (size_t t = 1; t < tasks; ++t) jobs.push_back(pool_submit([&fn, n, t, tasks]() { fn(n * t / tasks, n * (t + 1) / tasks); }));
+    std::exception_ptr failed;
+    try {
+        fn((size_t)0, n / tasks);
+    } catch (...) {
+        failed = std::current_exception();
+    }
+    for (auto& j : jobs) {  // every chunk is done before anything unwinds past what they write
         try {
-            jobs.push_back(run_async([&fn, n, t, tasks]() { fn(n * t / tasks, n * (t + 1) / tasks); }));
-        } catch (const std::system_error&) {
-            here.push_back(t);
+            pool_wait(j);
+        } catch (...) {
+            if (!failed) failed = std::current_exception();
         }
     }
-    try {
-        for (size_t t : here) fn(n * t / tasks, n * (t + 1) / tasks);
-    } catch (...) {
-        for (auto& j : jobs) j.wait();
-        throw;
-    }
-    for (auto& j : jobs) j.get();
+    if (failed) std::rethrow_exception(failed);
 }
 
 // A team of threads (the caller is member 0) that runs fn(member, team) and meets at team.barrier() between the

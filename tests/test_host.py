@@ -278,6 +278,31 @@ def test_reference_tree_does_not_depend_on_the_build_threads(ra, monkeypatch):
     assert np.array_equal(many.leaf_order(), one.leaf_order())
 
 
+def test_a_forked_child_builds_scenes_with_a_pool_of_its_own(ra):
+    """The set-up's tasks run on a pool of threads that sleeps between scenes (host/worker.cpp).  fork() copies none of
+    them into the child: the child must start its own at its first task — not queue work for threads that do not
+    exist, nor wait on the parent's condition variables — and both processes must end without joining anything."""
+    import os
+    ra.Scene(ra.load_scene(scene_path("teapot"), 1.5), ra.RT_DEVICE_NONE)  # the parent's pool exists and is asleep
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            s = ra.Scene(ra.load_scene(scene_path("lucy"), 1.5), ra.RT_DEVICE_NONE)
+            os.write(w, str(s.info().n_nodes).encode())
+        finally:
+            os._exit(0)
+    os.close(w)
+    import select
+    ready, _, _ = select.select([r], [], [], 120)
+    assert ready, "the forked child hangs"
+    assert os.read(r, 64) == b"6227"
+    os.waitpid(pid, 0)
+    os.close(r)
+    # and the parent's pool still works
+    assert ra.Scene(ra.load_scene(scene_path("lucy"), 1.5), ra.RT_DEVICE_NONE).info().n_nodes == 6227
+
+
 def test_host_only_scene_refuses_to_render(ra):
     s = ra.Scene(ra.load_scene(scene_path("quads"), 1.5), ra.RT_DEVICE_NONE)
     with pytest.raises(ra.api.RtError, match="host-only"):
