@@ -35,8 +35,8 @@ struct BuildKnobs {
 };
 
 bool segv_trace_enabled();  // RT_SEGV_TRACE was set when the library was loaded
-// No worker threads for the work that follows (BuildKnobs::one_thread; process-wide, set by rt_scene_create for the
-// length of the call): forks are not made, teams have one member, chunked loops one chunk.
+// No worker threads for the work that follows (BuildKnobs::one_thread; process-wide, set from the knob by every
+// rt_load_scene and rt_scene_create): tasks run where they are submitted, teams have one member, chunked loops one chunk.
 void set_workers_disabled(bool off);
 bool workers_disabled();
 // this thread's alternate signal stack for as long as the object lives (nothing unless segv_trace_enabled())
