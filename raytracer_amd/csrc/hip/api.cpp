@@ -27,6 +27,13 @@ extern int g_verbose;
 void write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t width, uint32_t height);
 }  // namespace rt
 
+namespace rt {
+const char* tuning_env(const char* name) {
+    static const bool tuning = getenv("RT_TUNE") != nullptr;
+    return tuning ? getenv(name) : nullptr;
+}
+}  // namespace rt
+
 using namespace rt;
 
 namespace {
@@ -1057,7 +1064,7 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_r
                 HIP_CHECK(hipMemcpy(&c, sl.d_counters, sizeof c, hipMemcpyDeviceToHost));
                 stats->segments = c.segments, stats->node_visits = c.node_visits, stats->tri_tests = c.tri_tests;
                 stats->sphere_tests = c.sphere_tests, stats->quad_tests = c.quad_tests;
-                if (getenv("RT_STAGE_DEBUG")) print_stage_debug(c);
+                if (tuning_env("RT_STAGE_DEBUG")) print_stage_debug(c);
             }
         }
         return 0;

@@ -34,4 +34,9 @@ hipError_t launch_primary64(const DevScene& sc, uint32_t width, uint32_t height,
 hipError_t launch_primary32(const DevScene& sc, uint32_t width, uint32_t height, uint32_t tree_depth,
                             int32_t* d_prim_id, double* d_t, hipStream_t stream);
 
+// The launch path's tuning and debugging knobs (RT_SHADE_T, RT_NODE_BIAS, RT_TAIL_K, RT_FIRST_CHUNK, RT_NO_W6,
+// RT_SWAP_T, RT_WF_DEBUG, RT_STAGE_DEBUG: tools/).  They are looked up only in a process that had RT_TUNE set at its
+// first launch — the tools set it —: a caller's render calls read no environment (api.cpp).
+const char* tuning_env(const char* name);
+
 }  // namespace rt

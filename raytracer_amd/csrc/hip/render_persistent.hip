@@ -620,9 +620,9 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // node trip is then cheap beside a shade trip, and the shade stage had better wait for more lanes: teapot.yaml
     // +3.3 %, dual.yaml +1.6 %, where lucy.yaml would lose 2.7 %; trees of spheres and quads, whose rays nearly all
     // enter the tree, take 48: one-weekend +3.5 %, random-spheres +6 %, final-scene +3 %)
-    plan.shade_threshold = getenv("RT_SHADE_T") ? atoi(getenv("RT_SHADE_T"))
+    plan.shade_threshold = tuning_env("RT_SHADE_T") ? atoi(tuning_env("RT_SHADE_T"))
                            : (sc.tree_kind != 1u ? 48 : (tree_depth <= 18u ? 44 : 36));
-    plan.node_bias = getenv("RT_NODE_BIAS") ? atoi(getenv("RT_NODE_BIAS")) : 2;
+    plan.node_bias = tuning_env("RT_NODE_BIAS") ? atoi(tuning_env("RT_NODE_BIAS")) : 2;
     plan.tiles_x = (rp.width + 7u) >> 3;
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
     plan.my_strata =
@@ -634,7 +634,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // With a tree: four chunks' worth, eight for the small trees (up to 18 levels) whose scenes run at six waves per
     // SIMD with short node trips — there the finer tail pays more (measured on the six-wave kernel, RT_TAIL_K 4 / 8:
     // teapot.yaml 6450 / 6605, dual.yaml 6605 / 6815 Msamples/s; lucy.yaml 13580 / 13500, cornell_lucy.yaml 4401 / 4396).
-    const uint32_t tail_chunks = getenv("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(getenv("RT_TAIL_K")))
+    const uint32_t tail_chunks = tuning_env("RT_TAIL_K") ? (uint32_t)std::max(0, atoi(tuning_env("RT_TAIL_K")))
                                                      : (sc.has_tree ? (tree_depth <= 18u ? 8u : 4u) : 1u);
     // Frames of 512 strata and more start with chunks twice as large (+1 %: fewer flushes, longer stays on a tile).
     // The large meshes (trees deeper than 18 levels) take larger ones still, and take them for the strata slices of
@@ -644,7 +644,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // dual.yaml's 1/8 slice at 32 takes 55 ms awaited instead of 40 (a heavy chunk late in the frame), 1/4 at 64: 107 for 76.
     const bool large_mesh = sc.has_tree && tree_depth > 18u;
     const uint32_t first_chunk =
-        getenv("RT_FIRST_CHUNK") ? (uint32_t)std::max(2, atoi(getenv("RT_FIRST_CHUNK")))
+        tuning_env("RT_FIRST_CHUNK") ? (uint32_t)std::max(2, atoi(tuning_env("RT_FIRST_CHUNK")))
         : large_mesh             ? (plan.my_strata >= 256u ? 4u * kChunkStrata : (plan.my_strata >= 128u ? 2u * kChunkStrata : kChunkStrata))
                                  : (plan.my_strata >= 512u ? 2u * kChunkStrata : kChunkStrata);
     uint32_t done = 0, groups = 0;
@@ -675,7 +675,7 @@ hipError_t launch_render_persistent(const DevScene& sc, const DevRenderParams& r
     // Mesh scenes whose blocks leave room for a sixth per CU run the six-wave build (see the top of this file), with
     // the stack's levels beyond kLdsStackCap in the overflow array when the tree is deeper than that (a caller
     // without one — rt_render_device_noalloc — then stays with the default build).
-    static const bool no_w6 = getenv("RT_NO_W6") != nullptr;  // A/B aid: the five-wave kernel throughout
+    static const bool no_w6 = tuning_env("RT_NO_W6") != nullptr;  // A/B aid: the five-wave kernel throughout
     PersistentPlan w6 = plan;
     w6.stack_levels = std::min(plan.stack_levels, kLdsStackCap);
     w6.stack_overflow = d_stack_overflow;

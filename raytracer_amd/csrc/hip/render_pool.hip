@@ -337,7 +337,7 @@ hipError_t launch_render_pool(const DevScene& sc, const DevRenderParams& rp, uin
                               bool stats, hipStream_t stream) {
     if (!pool_kernel_supports(rp.width, rp.height, tree_depth) || rp.max_depth > 63u) return hipErrorInvalidValue;
     PoolPlan plan;
-    plan.swap_threshold = getenv("RT_SWAP_T") ? atoi(getenv("RT_SWAP_T")) : 16;
+    plan.swap_threshold = tuning_env("RT_SWAP_T") ? atoi(tuning_env("RT_SWAP_T")) : 16;
     plan.tiles_x = (rp.width + 7u) >> 3;
     plan.n_tiles = plan.tiles_x * ((rp.height + 7u) >> 3);
     plan.my_strata =

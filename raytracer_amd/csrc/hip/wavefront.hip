@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "device_rt.h"
+#include "kernels.h"
 
 namespace rt {
 
@@ -242,7 +243,7 @@ hipError_t render_wavefront(WavefrontState& st, const DevScene& sc, const DevRen
             launches += 2;
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if (getenv("RT_WF_DEBUG")) {  // queue length per bounce level of this batch
+        if (tuning_env("RT_WF_DEBUG")) {  // queue length per bounce level of this batch
             std::vector<uint32_t> host(levels + 1);
             if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
             if ((e = hipMemcpy(host.data(), st.buf.counts, host.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) return e;

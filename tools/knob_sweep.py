@@ -1,6 +1,7 @@
 """Sweep the persistent kernel's scheduling knobs (read with getenv at every launch) per scene, in one process.
 usage: python tools/knob_sweep.py SCENE...   (on the GPU box)"""
 import os, sys
+os.environ["RT_TUNE"] = "1"  # the library reads its tuning knobs only then (hip/kernels.h tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import raytracer_amd as ra

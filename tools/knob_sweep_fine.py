@@ -1,5 +1,6 @@
 """Shade threshold in steps of 4 at the default node bias (see knob_sweep.py).  usage: python tools/knob_sweep_fine.py SCENE..."""
 import os, sys
+os.environ["RT_TUNE"] = "1"  # the library reads its tuning knobs only then (hip/kernels.h tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import raytracer_amd as ra

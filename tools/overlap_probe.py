@@ -4,6 +4,7 @@
 usage: python tools/overlap_probe.py [--slice 8] [--frames 12] [--tail 0,1,4] SCENE...   (on the GPU box)"""
 import argparse
 import os
+os.environ["RT_TUNE"] = "1"  # the library reads its tuning knobs only then (hip/kernels.h tuning_env)
 import sys
 import time
 

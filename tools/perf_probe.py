@@ -3,6 +3,7 @@
 Per scene: tree/loose info, per-segment work counts from the counting build, the stage split of the counting
 build (--stages: RT_STAGE_DEBUG output on stderr), and throughput at each --sn."""
 import argparse, os, sys
+os.environ["RT_TUNE"] = "1"  # the library reads its tuning knobs only then (hip/kernels.h tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
