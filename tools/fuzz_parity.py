@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=60)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--examples", action="store_true", help="the eight example generators (scene/example.rs) with random seeds instead of scene files")
+ap.add_argument("--extras", action="store_true", help="every third scene also: strata slices, device-built tree, no tree")
 ap.add_argument("--only", type=int, default=-1, help="compare this scene of the sequence only (the others are drawn and skipped)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
@@ -139,6 +140,51 @@ def compare(k, label, desc, scene, oracle, w, h, sn, flips_allowed, dt_max, dt_a
           f"render nodes {info.render_nodes:4d}: {'ok' if not notes else '; '.join(notes)}", flush=True)
 
 
+def extras(k, path, scene, w, h, sn):
+    """Further properties: strata slices add up to the frame (what several GPUs render), a render tree
+    built on the GPU finds the same hits and the same frame as the host-built one; and no tree at all (--no-bvh) renders
+    the oracle's --no-bvh frame."""
+    global bad
+    notes = []
+    n = sn * sn
+    whole, st = scene.render(w, h, sn, collect_stats=True)
+    parts = [scene.render(w, h, sn, stratum_begin=r, stratum_step=3, collect_stats=True) for r in range(3)]
+    if sum(p[1].samples for p in parts) != st.samples or not same_image(sum(p[0].astype(np.float64) for p in parts), whole, n):
+        notes.append("three strata slices do not add up to the frame")
+    ids, t = scene.primary_hits(w, h, precision=32)
+    for mode in ("device", False):
+        other = ra.Scene(ra.load_scene(path, w / h, use_bvh=mode), 0)
+        if mode == "device" and other.info().device_build != 1:
+            notes.append("the device build was not used")
+        oi, ot = other.primary_hits(w, h, precision=32)
+        # (one tree's boxes let a ray reach a primitive that another tree's boxes cull only where the hit lies on
+        # the box's face to within rounding: ids may swap among equal-t hits, t may not move)
+        if mode == "device" and (np.abs(np.where(ids >= 0, t, 0) - np.where(oi >= 0, ot, 0)).max() > 1e-9 or ((ids >= 0) != (oi >= 0)).any()):
+            notes.append(f"use_bvh={mode}: f32 first hits differ from the host-built tree's")
+        img, st2 = other.render(w, h, sn, collect_stats=True)
+        if mode is False:
+            # Without a tree the reference keeps everything in ONE leaf, whose box every ray of interest crosses: a
+            # negative-radius sphere (the hollow glass of tests/synth.py) is then met by rays that its small leaf of
+            # the tree would have kept away (Q8) — the frame is the reference's --no-bvh frame, not the tree's.
+            want, _ = ref.RefScene.from_yaml(path, w / h, use_bvh=False).render(w, h, sn, threads=16, sampler=1)
+            dev = np.abs(img.astype(np.float64) - want).max(axis=-1) / n
+            moved = dev > SAME_PATH
+            if st2.samples != st.samples or moved.sum() > 3 + PARTED_FRACTION * w * h * n or \
+                    np.sqrt(np.mean((img.astype(np.float64)[~moved] - want[~moved]) ** 2)) / n > SAME_PATH_RMSE:
+                notes.append(f"use_bvh=False: the frame differs from the oracle's --no-bvh frame ({int(moved.sum())} pixels moved)")
+        elif st2.samples != st.samples or not same_image(img, whole, n):
+            notes.append(f"use_bvh={mode}: the frame differs from the host-built tree's")
+        other.close()
+    bad += bool(notes)
+    print(f"{k:3d} extras: {'ok' if not notes else '; '.join(notes)}", flush=True)
+
+
+def same_image(a, b, n):  # tests/test_gpu_parity.py _same_image: equal up to f32 summation order and the rare path that flips
+    a, b = np.asarray(a, np.float64) / n, np.asarray(b, np.float64) / n
+    differs = np.any(np.abs(a - b) > 1e-5 * np.maximum(np.abs(a), 1.0), axis=-1)
+    return differs.mean() <= 2e-3 + 3.0 / differs.size and abs(a.mean() - b.mean()) <= 1e-3 * max(a.mean(), 1e-6)
+
+
 for k in range(args.scenes):
     if args.examples:
         # (the generators' own cameras; test_examples.py's bars for the first hits: the cornell examples' camera sits on
@@ -169,6 +215,8 @@ for k in range(args.scenes):
         scene = ra.Scene(desc, 0)
         oracle = ref.RefScene.from_yaml(path, w / h)
         compare(k, f"{kind:18s} seed {seed:10d}", desc, scene, oracle, w, h, sn, max(4, 1e-3 * w * h), F32_DT_MAX, 4)
+        if args.extras and k % 3 == 0:
+            extras(k, path, scene, w, h, sn)
         scene.close()
 print(f"{args.scenes} scenes in {time.time() - t_start:.0f} s, {bad} with a missed bar.  Images: {parted_total} of {paths_total} paths "
       f"parted ways ({parted_total / max(paths_total, 1):.1e}; worst frame {worst['parted']:.1e}, bar {PARTED_FRACTION} + 3), rmse of the pixels that did "
