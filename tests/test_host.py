@@ -303,6 +303,35 @@ def test_a_forked_child_builds_scenes_with_a_pool_of_its_own(ra):
     assert ra.Scene(ra.load_scene(scene_path("lucy"), 1.5), ra.RT_DEVICE_NONE).info().n_nodes == 6227
 
 
+def test_scenes_set_up_from_several_threads_at_once(ra):
+    """Callers on several host threads (ctypes releases the GIL) share the set-up's one pool: their tasks queue side
+    by side, every waiter helps with whatever is queued — and each gets the scene it would have got alone."""
+    import hashlib
+    import threading
+
+    def signature(name):
+        s = ra.Scene(ra.load_scene(scene_path(name), 16 / 9), ra.RT_DEVICE_NONE)
+        i = s.info()
+        return (i.n_nodes, i.n_leaves, i.render_nodes, i.render_depth, hashlib.sha1(s.leaf_order().tobytes()).hexdigest())
+
+    names = ("lucy", "teapot", "dual", "cornell_lucy")
+    alone = {n: signature(n) for n in names}
+    wrong = []
+
+    def caller(k):
+        for it in range(4):
+            n = names[(k + it) % len(names)]
+            if signature(n) != alone[n]:
+                wrong.append((k, it, n))
+
+    threads = [threading.Thread(target=caller, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not wrong
+
+
 def test_host_only_scene_refuses_to_render(ra):
     s = ra.Scene(ra.load_scene(scene_path("quads"), 1.5), ra.RT_DEVICE_NONE)
     with pytest.raises(ra.api.RtError, match="host-only"):
