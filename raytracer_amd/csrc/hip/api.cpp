@@ -847,7 +847,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
             }
             s->info.device_build = build_device >= 0 ? 1u : 0u;
             if (build_device >= 0) {
-                // the device build runs on a thread of its own beside the reference-topology build: the context is
+                // the device build runs as a task of the pool beside the reference-topology build: the context is
                 // created here first, on this thread, before any other thread exists (see above)
                 DeviceGuard first_use(build_device);
                 HIP_CHECK(hipFree(nullptr));

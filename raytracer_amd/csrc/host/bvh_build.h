@@ -41,7 +41,7 @@ struct Bvh {
 // Where a build puts its nodes.  The top levels of both builders hand one child to another thread, and every task
 // builds into a piece of its own; a piece that was built elsewhere is ATTACHED where a sequential build would have
 // laid its nodes (self, left subtree, right subtree), i.e. it takes its range of indices, and its nodes are copied
-// once, at the end, into the one array (lay_out, big pieces on threads of their own).  Indices inside a piece count
+// once, at the end, into the one array (lay_out, big pieces as tasks of their own).  Indices inside a piece count
 // from the piece's first node.  (The pieces used to be copied into their parent at every join: a node of lucy's
 // tree was copied four times, the last copies on one thread while the others had ended — 6 of the render tree's 19 ms.)
 struct TreePiece {

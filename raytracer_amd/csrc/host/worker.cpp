@@ -178,7 +178,7 @@ bool g_trace_on = false;  // written once, at library load
 
 // Debugging aid (RT_SEGV_TRACE=1): the faulting thread's stack on SIGSEGV / SIGBUS / SIGABRT.  The message goes out
 // before the unwinder runs (an unwinder that faults on a damaged stack must not take the message with it), and the
-// handler runs on the thread's alternate stack where it has one (the loading thread, every run_async worker).  A
+// handler runs on the thread's alternate stack where it has one (the loading thread, the pool's threads, a team's members).  A
 // fault on a thread that blocks the signal — the HIP runtime's own threads block all of them at their entry — never
 // gets here: the kernel ends the process with the default action.
 void fatal_signal(int sig) {
